@@ -1,0 +1,113 @@
+/*
+ * alsmi — MI355X (gfx950) kernels for the ALS / IMC / DirtyIMC update loop.
+ *
+ * C ABI of libalsmi.so.  The upstream project (GrierPhillips/Recommendation-Models)
+ * is pure Python and has no FFI of its own; each entry point below replaces the
+ * numpy/scipy arithmetic of the cited reference lines and is bound from Python
+ * with ctypes.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative ALSMI_E* code on failure;
+ *    alsmi_last_error() gives the message of the calling thread's last failure.
+ *    No C++ exception crosses the boundary.
+ *  - pointers named *_host are host memory, everything else is DEVICE memory on
+ *    the current HIP device, owned by the caller, and only used during the call
+ *    (kernels are enqueued on `stream`; the call does not synchronise unless it
+ *    says so).
+ *  - `dtype` is ALSMI_F32 or ALSMI_F64 and fixes the element type of every
+ *    `void*` factor / rating / attribute buffer of that call.
+ *  - factor tables are ROW-major [n x ld] with ld = alsmi_padded_rank(rank)
+ *    (16, 32, 64 or 128); columns rank..ld-1 must be zero.  The reference keeps
+ *    (rank, n) C-order arrays (src/als.py:149-151); the host binding transposes.
+ *  - sparse structure: `indptr` int64 [n_rows+1], `indices` int32 [nnz] sorted
+ *    inside a row, `vals` [nnz] of dtype.  For the item side pass the CSC arrays.
+ *  - calls that share a plan or a workspace must not overlap in time.
+ */
+#ifndef ALSMI_H
+#define ALSMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALSMI_F32 0
+#define ALSMI_F64 1
+
+#define ALSMI_OK 0
+#define ALSMI_EINVAL (-1)   /* bad argument (shape, dtype, rank, null pointer) */
+#define ALSMI_EHIP (-2)     /* a HIP runtime call failed */
+#define ALSMI_ENOMEM (-3)   /* allocation failed */
+
+typedef struct alsmi_plan alsmi_plan;
+
+/* Library version (major*10000 + minor*100 + patch). */
+int alsmi_version(void);
+
+/* Message of the last error raised on the calling thread ("" if none). */
+const char *alsmi_last_error(void);
+
+/* Row stride (in elements) of a factor table for `rank`: the next of
+ * 16/32/64/128 that is >= rank; 0 if rank is < 1 or > 128. */
+int alsmi_padded_rank(int rank);
+
+/* ---- ALS half-sweep: src/als.py:173-300 (_update_parallel,
+ * _thread_update_features, _update_one, make_item_submats, make_user_submats) --
+ *
+ * A plan is the schedule of one side's half-sweep over rows
+ * [row_begin, row_end) of a structure with n_rows_total rows: rows ordered by
+ * degree, rows longer than `chunk` entries cut into chunks whose partial normal
+ * equations are combined in a fixed order.  It replaces the reference's
+ * np.array_split chunking (src/als.py:155-159).  It owns a little device memory
+ * (work lists and the partial-sum workspace) allocated at creation on the
+ * current device; no call on the plan allocates afterwards.
+ * `chunk` = 0 picks the default.  Synchronous. */
+int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host,
+                      int64_t n_rows_total, int64_t row_begin, int64_t row_end,
+                      int rank, int dtype, int chunk);
+int alsmi_plan_destroy(alsmi_plan *plan);
+/* Any out pointer may be NULL. */
+int alsmi_plan_info(const alsmi_plan *plan, int64_t *n_rows, int64_t *n_heavy_rows,
+                    int64_t *n_chunks, int64_t *workspace_bytes);
+
+/* For every row r of the plan:
+ *   A = sum_t f_t f_t^T + alpha*n_r*I,  b = sum_t vals_t f_t,  dst[r] = A^-1 b
+ * with f_t = src_factors[indices[t]] over the row's n_r stored entries
+ * (src/als.py:243-247); an empty row or a matrix that is not positive definite
+ * gives a zero vector (the reference's LinAlgError branch, src/als.py:248-249).
+ * Rows outside the plan's range are not touched. */
+int alsmi_half_sweep(alsmi_plan *plan, const int64_t *indptr, const int32_t *indices,
+                     const void *vals, const void *src_factors, int64_t n_src,
+                     void *dst_factors, double alpha, void *stream);
+
+/* Debug / test aid: the assembled normal equations of the plan's rows before the
+ * solve.  A_out [n_rows x ld x ld], b_out [n_rows x ld], both indexed by
+ * (row - row_begin), natural (unpermuted) order, ridge included. */
+int alsmi_normal_equations(alsmi_plan *plan, const int64_t *indptr, const int32_t *indices,
+                           const void *vals, const void *src_factors, int64_t n_src,
+                           void *A_out, void *b_out, double alpha, void *stream);
+
+/* ---- pair predictions and squared error: src/als.py:161-165 (train RMSE),
+ * :316-321 (_predict), :383-388 (score) ------------------------------------
+ *
+ * pred_p = <row_factors[users[p]], col_factors[items[p]]> for p < n_pairs.
+ * pred_out (dtype, [n_pairs]) may be NULL.  If vals is not NULL, sse_out[0]
+ * (one double) receives sum_p (vals[p]-pred_p)^2 accumulated in fp64 in a fixed
+ * order.  workspace: at least alsmi_sddmm_workspace_bytes() bytes. */
+size_t alsmi_sddmm_workspace_bytes(void);
+int alsmi_sddmm(int dtype, int rank, int64_t n_pairs, const int32_t *users,
+                const int32_t *items, const void *row_factors, const void *col_factors,
+                const void *vals, void *pred_out, double *sse_out, void *workspace,
+                void *stream);
+
+/* Row index of every stored entry of rows [row_begin,row_end) (the `users`
+ * array of data.nonzero(), src/als.py:161), written to rows_out[0 .. nnz_local). */
+int alsmi_expand_rows(const int64_t *indptr, int64_t row_begin, int64_t row_end,
+                      int32_t *rows_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALSMI_H */

@@ -1,0 +1,203 @@
+"""ALS-WR matrix factorisation estimator on MI355X.
+
+Same estimator surface as the reference's ``src/als.py`` ``ALS`` class
+(constructor arguments, ``fit / fit_transform / _predict / predict_one /
+predict_all / score / update_user / add_user``, attributes ``user_feats``,
+``item_feats``, ``data``, ``reconstruction_err_``); the per-row normal equations,
+their solves and every pair prediction run in libalsmi's HIP kernels.
+"""
+import os
+import warnings
+
+import numpy as np
+import scipy.sparse as sps
+from sklearn.base import BaseEstimator
+from sklearn.utils.validation import check_is_fitted, check_random_state
+
+from . import device as dev
+from .engine import AlsEngine
+from .utils import (_check_x, _check_y, root_mean_squared_error, triplets_to_csr)
+
+
+def _default_group():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.group.WORLD
+    return None
+
+
+class ALS(BaseEstimator):
+    """Alternating least squares with weighted-lambda regularisation.
+
+    Parameters
+    ----------
+    rank, alpha, tol, random_state, n_jobs, verbose
+        As in the reference (src/als.py:75-85).  ``n_jobs`` is accepted for
+        compatibility; the rows of a half-sweep are spread over the GPU (and over
+        the ranks of an initialised ``torch.distributed`` group) instead of joblib
+        workers.
+    dtype : {'float64', 'float32'}
+        Arithmetic type of the device path.  float64 reproduces the reference to
+        ~1e-10; float32 is the throughput mode (factors within ~1e-4).
+    max_iter : int or None
+        When given, run exactly this many sweeps instead of the reference's
+        ``while diff > tol`` rule.
+    """
+
+    def __init__(self, rank=10, alpha=0.1, tol=0.001, random_state=None,
+                 n_jobs=1, verbose=0, dtype='float64', max_iter=None):
+        self.rank = rank
+        self.alpha = alpha
+        self.tol = tol
+        self.random_state = random_state
+        if n_jobs == -1:
+            n_jobs = os.cpu_count()
+        self.n_jobs = n_jobs
+        self.verbose = verbose
+        self.dtype = dtype
+        self.max_iter = max_iter
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X, y, shape=None):
+        """Fit the model; see ``fit_transform`` (src/als.py:87-107)."""
+        _, _ = self.fit_transform(X, y, shape=shape)
+        return self
+
+    def _build_data(self, X, y, shape):
+        """Ratings as a canonical CSR matrix (src/als.py:132-142)."""
+        if (y.ndim < 2 or y.shape[0] == 1) and not shape:
+            raise ValueError('When y is a scalar or 1-D array shape must be' +
+                             'provided.')
+        users, items = _check_x(X)
+        if not sps.issparse(y):
+            indptr, indices, vals = triplets_to_csr(users, items, y, shape)
+            data = sps.csr_matrix((vals, indices, indptr), shape=tuple(shape))
+        else:
+            data = y.tocsr().astype(np.float64)
+            if data is y:
+                data = data.copy()
+            data.sum_duplicates()
+            data.eliminate_zeros()
+            data.sort_indices()
+        return data
+
+    def fit_transform(self, X, y, shape=None):
+        """Factorise the ratings; returns ``(user_feats, item_feats)`` of shapes
+        (rank, n_users) and (rank, n_items) (src/als.py:109-171)."""
+        data = self._build_data(X, y, shape)
+        random_state = check_random_state(self.random_state)
+        n, m = data.shape
+
+        # initial factors: uniform random items with row 0 = mean rating of the
+        # item, zero users (src/als.py:143-152); the MT19937 stream stays on the host
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            counts = np.bincount(data.indices, minlength=m)
+            sums = np.bincount(data.indices, weights=data.data, minlength=m)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                item_avg = sums / counts
+        item_avg[np.isnan(item_avg)] = 0
+        self.item_feats = random_state.rand(self.rank, m)
+        self.item_feats[0] = item_avg
+        self.user_feats = np.zeros((self.rank, n))
+        self.data = data
+
+        engine = AlsEngine(data.indptr, data.indices, data.data, (n, m), self.rank, self.alpha,
+                           dtype=self.dtype, group=_default_group())
+        engine.set_factors(self.user_feats, self.item_feats)
+        rmse = float('inf')
+        diff = rmse
+        sweeps = 0
+        self.rmse_history_ = []
+        while (diff > self.tol) if self.max_iter is None else (sweeps < self.max_iter):
+            engine.half_sweep_users()
+            engine.half_sweep_items()
+            new_rmse = engine.train_rmse()
+            diff = rmse - new_rmse
+            rmse = new_rmse
+            sweeps += 1
+            self.rmse_history_.append(new_rmse)
+            if self.verbose:
+                print('sweep %d: train rmse %.6f' % (sweeps, new_rmse))
+            if not np.isfinite(new_rmse):
+                break
+        self.n_iter_ = sweeps
+        self.user_feats, self.item_feats = engine.get_factors()
+        self.reconstruction_err_ = self.score(X, y)
+        return self.user_feats, self.item_feats
+
+    # -------------------------------------------------------------- predict
+    def _pair_predictions(self, users, items):
+        device = dev.require_gpu()
+        import torch
+        users = np.asarray(users).ravel()
+        items = np.asarray(items).ravel()
+        n, m = self.user_feats.shape[1], self.item_feats.shape[1]
+        if users.size and (users.min() < -n or users.max() >= n or
+                           items.min() < -m or items.max() >= m):
+            raise IndexError('user/item index out of range')
+        users = np.where(users < 0, users + n, users).astype(np.int32)
+        items = np.where(items < 0, items + m, items).astype(np.int32)
+        U = dev.factors_to_device(self.user_feats, self.dtype, device)
+        V = dev.factors_to_device(self.item_feats, self.dtype, device)
+        pred, _ = dev.sddmm(self.rank, torch.from_numpy(users).to(device),
+                            torch.from_numpy(items).to(device), U, V)
+        return pred.to(torch.float64).cpu().numpy()
+
+    def _predict(self, X):
+        """Predictions for arrays of (user, item) pairs (src/als.py:302-321)."""
+        check_is_fitted(self, ['item_feats', 'user_feats'])
+        users, items = _check_x(X)
+        return self._pair_predictions(users, items)
+
+    def predict_one(self, user, item):
+        """Prediction for one pair, as a length-1 array (src/als.py:323-345)."""
+        return self._predict((np.array([user]), np.array([item])))
+
+    def predict_all(self, user):
+        """Predictions of every item for one user (src/als.py:347-364)."""
+        users = np.repeat(user, self.data.shape[1])
+        items = np.arange(self.data.shape[1])
+        return self._predict((users, items))
+
+    def score(self, X, y):
+        """NEGATIVE root mean squared error on the given pairs (src/als.py:366-388)."""
+        check_is_fitted(self, ['item_feats', 'user_feats'])
+        users, items = _check_x(X)
+        r_ = _check_y(y, users, items)
+        pred = self._pair_predictions(users, items)
+        return -root_mean_squared_error(r_, pred)
+
+    # ------------------------------------------------------ online updates
+    def update_user(self, user, item, value):
+        """Store a new rating and re-solve that user's factor vector against the
+        current item factors.
+
+        The reference delegates this to an external ``fit_als.py`` script that is
+        not part of its repository (src/als.py:390-422); here it is the same
+        single-row normal-equation solve the sweep uses, run on the device."""
+        check_is_fitted(self, ['item_feats', 'user_feats'])
+        device = dev.require_gpu()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', sps.SparseEfficiencyWarning)
+            self.data[user, item] = value
+        self.data.eliminate_zeros()
+        self.data.sort_indices()
+        row = self.data[user]
+        side = dev.SparseSide(np.array([0, row.nnz], dtype=np.int64), row.indices, row.data, 1,
+                              self.data.shape[1], self.dtype, device)
+        plan = dev.SweepPlan(side, self.rank)
+        V = dev.factors_to_device(self.item_feats, self.dtype, device)
+        out = V.new_zeros((1, V.shape[1]))
+        plan.half_sweep(V, out, self.alpha)
+        self.user_feats[:, user] = dev.factors_to_host(out, self.rank)[:, 0]
+        plan.close()
+
+    def add_user(self):
+        """Append an empty user: one more row of ``data`` and a zero column of
+        ``user_feats`` (src/als.py:424-439)."""
+        check_is_fitted(self, ['item_feats', 'user_feats'])
+        shape = self.data.shape
+        self.data = sps.vstack([self.data, sps.csr_matrix((1, shape[1]))], format='csr')
+        new_col = np.zeros((self.rank, 1))
+        self.user_feats = np.hstack((self.user_feats, new_col))

@@ -1,0 +1,196 @@
+"""Device-side containers and thin wrappers over the libalsmi entry points.
+
+torch is used for device memory, streams and (in ``dist.py``) collectives only;
+every arithmetic step is a libalsmi kernel.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('alsmi needs a HIP device (torch.cuda.is_available() is False); '
+                           'there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def torch_dtype(np_dtype):
+    return torch.float32 if np.dtype(np_dtype) == np.float32 else torch.float64
+
+
+def padded_rank(rank):
+    kp = _lib.load().alsmi_padded_rank(int(rank))
+    if kp == 0:
+        raise ValueError('rank must be between 1 and 128, got %r' % (rank,))
+    return kp
+
+
+def factors_to_device(feats, dtype, device):
+    """(rank, n) host array, the reference's layout (src/als.py:149-151) ->
+    row-major [n x ld] device table with zero pad columns."""
+    feats = np.asarray(feats)
+    rank, n = feats.shape
+    kp = padded_rank(rank)
+    host = np.zeros((n, kp), dtype=dtype)
+    host[:, :rank] = feats.T
+    return torch.from_numpy(host).to(device)
+
+
+def factors_to_host(table, rank):
+    """[n x ld] device table -> (rank, n) float64 C-order host array."""
+    return np.ascontiguousarray(table[:, :rank].to(torch.float64).cpu().numpy().T)
+
+
+class SparseSide(object):
+    """One orientation of the ratings on the device: CSR for the user side,
+    CSC (as the CSR of the transpose) for the item side."""
+
+    def __init__(self, indptr, indices, vals, n_rows, n_cols, dtype, device):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        if indptr.shape != (n_rows + 1,):
+            raise ValueError('indptr must have n_rows + 1 entries')
+        nnz = int(indptr[-1])
+        if len(indices) != nnz or len(vals) != nnz:
+            raise ValueError('indices/vals do not match indptr')
+        indices = np.asarray(indices)
+        if nnz and (indices.min() < 0 or indices.max() >= n_cols):
+            raise ValueError('column index out of range')
+        self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), nnz
+        self.dtype = np.dtype(dtype)
+        self.indptr_host = indptr
+        self.indptr = torch.from_numpy(indptr).to(device)
+        self.indices = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).to(device)
+        self.vals = torch.from_numpy(np.ascontiguousarray(vals, dtype=self.dtype)).to(device)
+        self.device = device
+
+    def expand_rows(self, row_begin=0, row_end=None):
+        """Row id of every stored entry of the row range (int32, device)."""
+        if row_end is None:
+            row_end = self.n_rows
+        lo, hi = int(self.indptr_host[row_begin]), int(self.indptr_host[row_end])
+        out = torch.empty(hi - lo, dtype=torch.int32, device=self.device)
+        _lib.check(_lib.load().alsmi_expand_rows(_ptr(self.indptr), row_begin, row_end, _ptr(out),
+                                                 _stream()), 'alsmi_expand_rows')
+        return out
+
+
+class SweepPlan(object):
+    """Schedule of one side's half-sweep over rows [row_begin, row_end)."""
+
+    def __init__(self, side, rank, row_begin=0, row_end=None, chunk=0):
+        lib = _lib.load()
+        if row_end is None:
+            row_end = side.n_rows
+        self.side, self.rank = side, int(rank)
+        self.row_begin, self.row_end = int(row_begin), int(row_end)
+        self.kp = padded_rank(rank)
+        handle = ctypes.c_void_p(0)
+        with torch.cuda.device(side.device):
+            _lib.check(lib.alsmi_plan_create(
+                ctypes.byref(handle), side.indptr_host.ctypes.data_as(ctypes.c_void_p),
+                side.n_rows, self.row_begin, self.row_end, self.rank,
+                _lib.dtype_code(side.dtype), int(chunk)), 'alsmi_plan_create')
+        self._handle = handle
+
+    def info(self):
+        vals = [ctypes.c_int64(0) for _ in range(4)]
+        _lib.check(_lib.load().alsmi_plan_info(self._handle, *[ctypes.byref(v) for v in vals]),
+                   'alsmi_plan_info')
+        return dict(zip(('n_rows', 'n_heavy_rows', 'n_chunks', 'workspace_bytes'),
+                        (v.value for v in vals)))
+
+    def _check_tables(self, src, dst):
+        td = torch_dtype(self.side.dtype)
+        if src.dtype != td or src.dim() != 2 or src.shape[1] != self.kp or \
+                src.shape[0] < self.side.n_cols or not src.is_contiguous():
+            raise ValueError('source factor table must be contiguous [>=%d x %d] %s'
+                             % (self.side.n_cols, self.kp, td))
+        if dst is not None and (dst.dtype != td or dst.dim() != 2 or dst.shape[1] != self.kp or
+                                dst.shape[0] < self.side.n_rows or not dst.is_contiguous()):
+            raise ValueError('destination factor table must be contiguous [>=%d x %d] %s'
+                             % (self.side.n_rows, self.kp, td))
+
+    def half_sweep(self, src, dst, alpha):
+        """dst[r] = (sum f f^T + alpha n_r I)^-1 sum val f for the plan's rows."""
+        self._check_tables(src, dst)
+        s = self.side
+        if s.nnz == 0:
+            dst[self.row_begin:self.row_end].zero_()
+            return
+        _lib.check(_lib.load().alsmi_half_sweep(
+            self._handle, _ptr(s.indptr), _ptr(s.indices), _ptr(s.vals), _ptr(src),
+            max(int(src.shape[0]), 1), _ptr(dst), float(alpha), _stream()), 'alsmi_half_sweep')
+
+    def normal_equations(self, src, alpha):
+        """Test aid: (A [rows x ld x ld], b [rows x ld]) before the solve."""
+        self._check_tables(src, None)
+        s = self.side
+        n = self.row_end - self.row_begin
+        td = torch_dtype(s.dtype)
+        A = torch.zeros((n, self.kp, self.kp), dtype=td, device=s.device)
+        b = torch.zeros((n, self.kp), dtype=td, device=s.device)
+        _lib.check(_lib.load().alsmi_normal_equations(
+            self._handle, _ptr(s.indptr), _ptr(s.indices), _ptr(s.vals), _ptr(src),
+            int(src.shape[0]), _ptr(A), _ptr(b), float(alpha), _stream()),
+            'alsmi_normal_equations')
+        return A, b
+
+    def close(self):
+        if getattr(self, '_handle', None) is not None and self._handle.value:
+            _lib.load().alsmi_plan_destroy(self._handle)
+            self._handle = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_workspaces = {}
+
+
+def _sddmm_workspace(device):
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = int(_lib.load().alsmi_sddmm_workspace_bytes())
+        ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def sddmm(rank, users, items, row_table, col_table, vals=None, want_pred=True):
+    """pred_p = <row_table[users[p]], col_table[items[p]]>; with ``vals`` also the
+    sum of squared errors (a 1-element fp64 device tensor).  All device tensors."""
+    lib = _lib.load()
+    device = row_table.device
+    n_pairs = int(users.numel())
+    if users.dtype != torch.int32 or items.dtype != torch.int32 or items.numel() != n_pairs:
+        raise ValueError('users/items must be int32 device tensors of equal length')
+    if row_table.dtype != col_table.dtype:
+        raise ValueError('factor tables must share a dtype')
+    np_dtype = np.float32 if row_table.dtype == torch.float32 else np.float64
+    pred = torch.empty(n_pairs, dtype=row_table.dtype, device=device) if want_pred else None
+    sse = None
+    if vals is not None:
+        if vals.dtype != row_table.dtype or vals.numel() != n_pairs:
+            raise ValueError('vals must match the tables dtype and the pair count')
+        sse = torch.zeros(1, dtype=torch.float64, device=device)
+    _lib.check(lib.alsmi_sddmm(_lib.dtype_code(np_dtype), int(rank), n_pairs, _ptr(users),
+                               _ptr(items), _ptr(row_table), _ptr(col_table), _ptr(vals),
+                               _ptr(pred), _ptr(sse), _ptr(_sddmm_workspace(device)), _stream()),
+               'alsmi_sddmm')
+    return pred, sse

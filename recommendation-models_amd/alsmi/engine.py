@@ -1,0 +1,151 @@
+"""Device state and sweep driver of the ALS update loop (src/als.py:154-169).
+
+One ``AlsEngine`` lives in one process and drives one GPU.  With a
+``torch.distributed`` process group of size G the users and items are cut into G
+contiguous row ranges balanced by stored entries (the role of the reference's
+``np.array_split`` chunks, src/als.py:155-159); every rank updates its own ranges
+and each half-sweep ends with an all-gather of the updated factor rows (RCCL over
+xGMI when the backend is "nccl"), the training error with an all-reduce of the
+squared-error sum.
+"""
+import numpy as np
+import scipy.sparse as sps
+import torch
+
+from . import device as dev
+
+
+def split_by_nnz(indptr, parts):
+    """Boundaries of ``parts`` contiguous row ranges with (almost) equal numbers of
+    stored entries: int64 array of parts+1 row ids."""
+    indptr = np.asarray(indptr)
+    n = indptr.size - 1
+    total = int(indptr[-1])
+    targets = (np.arange(1, parts, dtype=np.int64) * total) // parts
+    cuts = np.searchsorted(indptr, targets, side='left')
+    bounds = np.concatenate(([0], cuts, [n])).astype(np.int64)
+    return np.maximum.accumulate(np.minimum(bounds, n))
+
+
+class LocalBackend(object):
+    """The HIP kernels on this process's GPU (the only product backend)."""
+
+    def __init__(self, device=None):
+        self.device = device if device is not None else dev.require_gpu()
+
+    def make_side(self, indptr, indices, vals, n_rows, n_cols, dtype):
+        return dev.SparseSide(indptr, indices, vals, n_rows, n_cols, dtype, self.device)
+
+    def make_plan(self, side, rank, chunk):
+        return dev.SweepPlan(side, rank, chunk=chunk)
+
+    def zeros(self, rows, cols, dtype):
+        return torch.zeros((rows, cols), dtype=dev.torch_dtype(dtype), device=self.device)
+
+    def sddmm(self, rank, users, items, row_table, col_table, vals, want_pred):
+        return dev.sddmm(rank, users, items, row_table, col_table, vals, want_pred)
+
+    def padded_rank(self, rank):
+        return dev.padded_rank(rank)
+
+
+class AlsEngine(object):
+    def __init__(self, indptr, indices, vals, shape, rank, alpha, dtype=np.float64,
+                 group=None, backend=None, chunk=0, csc=None):
+        self.backend = backend if backend is not None else LocalBackend()
+        self.n, self.m = int(shape[0]), int(shape[1])
+        self.rank, self.alpha = int(rank), float(alpha)
+        self.dtype = np.dtype(dtype)
+        self.group = group
+        if group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(group)
+            self.me = dist.get_rank(group)
+        else:
+            self.world, self.me = 1, 0
+        indptr = np.asarray(indptr, dtype=np.int64)
+        self.nnz = int(indptr[-1])
+        if csc is None:
+            mat = sps.csr_matrix((np.asarray(vals), np.asarray(indices), indptr),
+                                 shape=(self.n, self.m)).tocsc()
+            mat.sort_indices()
+            csc = (mat.indptr.astype(np.int64), mat.indices, mat.data)
+        cptr, cidx, cvals = csc
+        self.user_bounds = split_by_nnz(indptr, self.world)
+        self.item_bounds = split_by_nnz(cptr, self.world)
+        ulo, uhi = int(self.user_bounds[self.me]), int(self.user_bounds[self.me + 1])
+        ilo, ihi = int(self.item_bounds[self.me]), int(self.item_bounds[self.me + 1])
+        self.ulo, self.uhi, self.ilo, self.ihi = ulo, uhi, ilo, ihi
+        b = self.backend
+        a, z = int(indptr[ulo]), int(indptr[uhi])
+        self.csr = b.make_side(indptr[ulo:uhi + 1] - a, indices[a:z], vals[a:z], uhi - ulo,
+                               self.m, self.dtype)
+        a, z = int(cptr[ilo]), int(cptr[ihi])
+        self.csc = b.make_side(cptr[ilo:ihi + 1] - a, cidx[a:z], cvals[a:z], ihi - ilo, self.n,
+                               self.dtype)
+        self.plan_u = b.make_plan(self.csr, self.rank, chunk)
+        self.plan_i = b.make_plan(self.csc, self.rank, chunk)
+        self.kp = b.padded_rank(self.rank)
+        self.U = b.zeros(self.n, self.kp, self.dtype)
+        self.V = b.zeros(self.m, self.kp, self.dtype)
+        self.pair_rows = self.csr.expand_rows()  # local row ids of this rank's entries
+        self.local_nnz = self.csr.nnz
+
+    # ---- factors ------------------------------------------------------------
+    def set_factors(self, user_feats, item_feats):
+        """Host (rank, n) / (rank, m) arrays -> device tables."""
+        for table, feats in ((self.U, user_feats), (self.V, item_feats)):
+            host = np.zeros((feats.shape[1], self.kp), dtype=self.dtype)
+            host[:, :self.rank] = np.asarray(feats).T
+            table.copy_(torch.from_numpy(host))
+
+    def get_factors(self):
+        return dev.factors_to_host(self.U, self.rank), dev.factors_to_host(self.V, self.rank)
+
+    # ---- collectives --------------------------------------------------------
+    def _all_gather_rows(self, table, bounds):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        sizes = np.diff(bounds)
+        lo, hi = int(bounds[self.me]), int(bounds[self.me + 1])
+        if sizes.min() == sizes.max():
+            dist.all_gather_into_tensor(table, table[lo:hi], group=self.group)
+            return
+        width = int(sizes.max())
+        send = torch.zeros((width, table.shape[1]), dtype=table.dtype, device=table.device)
+        send[:hi - lo].copy_(table[lo:hi])
+        recv = torch.empty((self.world * width, table.shape[1]), dtype=table.dtype,
+                           device=table.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        for r in range(self.world):
+            if r != self.me and sizes[r]:
+                table[int(bounds[r]):int(bounds[r + 1])].copy_(
+                    recv[r * width:r * width + int(sizes[r])])
+
+    # ---- the loop body ------------------------------------------------------
+    def half_sweep_users(self):
+        self.plan_u.half_sweep(self.V, self.U[self.ulo:self.uhi], self.alpha)
+        self._all_gather_rows(self.U, self.user_bounds)
+
+    def half_sweep_items(self):
+        self.plan_i.half_sweep(self.U, self.V[self.ilo:self.ihi], self.alpha)
+        self._all_gather_rows(self.V, self.item_bounds)
+
+    def train_sse_async(self):
+        """Sum of squared errors over all stored entries as a 1-element fp64 device
+        tensor (src/als.py:161-165 before the mean and sqrt)."""
+        _, sse = self.backend.sddmm(self.rank, self.pair_rows, self.csr.indices,
+                                    self.U[self.ulo:self.uhi], self.V, self.csr.vals, False)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(sse, group=self.group)
+        return sse
+
+    def train_rmse(self):
+        sse = float(self.train_sse_async().cpu()[0])
+        return float(np.sqrt(sse / self.nnz)) if self.nnz else float('nan')
+
+    def sweep(self):
+        self.half_sweep_users()
+        self.half_sweep_items()

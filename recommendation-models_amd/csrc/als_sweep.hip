@@ -1,0 +1,640 @@
+// ALS half-sweep for gfx950: per-row normal equations on MFMA + in-wave Cholesky solve.
+//
+// Replaces the reference's per-row Python loop (src/als.py:173-300): for every row r
+//   A = sum_t f_t f_t^T + alpha n_r I,   b = sum_t val_t f_t,   x_r = A^-1 b.
+//
+// Data layout
+//   factor tables: row-major [n x KP], KP = padded rank (16/32/64/128), pad columns zero.
+//   One wave owns one row at a time.  Lane (g = lane>>4, q = lane&15) of a wave loads the
+//   NV = KP/16 consecutive elements q*NV .. q*NV+NV-1 of the factor row of neighbour
+//   4*step+g, so 16 lanes read one whole contiguous factor row and one wave instruction
+//   reads four rows.  Register e of that load is, over the 16 lanes q, a 16-column slice
+//   {q*NV+e} of the factor matrix — exactly the one-element-per-lane A and B operand of
+//   v_mfma_{f32,f64}_16x16x4 (k = the 4 neighbours of the step).  Tile (e,f) of the Gram
+//   matrix is therefore mfma(v[e], v[f]) with no LDS staging and no transpose; only the
+//   NV(NV+1)/2 tiles with e <= f are computed.
+//   The accumulators go through a wave-private LDS slab once (tile layout -> one matrix row
+//   per lane), the Cholesky factorisation, the forward substitution (fused) and the back
+//   substitution run inside the wave with v_readlane broadcasts — no barrier, no host round
+//   trip.
+//   Rows longer than `chunk` entries are cut into chunks; a first kernel writes each chunk's
+//   partial accumulators to a workspace slab and the solve kernel adds the slabs of a row in
+//   chunk order, so results do not depend on how rows are spread over waves or GPUs.
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "alsmi_common.h"
+
+namespace alsmi {
+
+__host__ __device__ constexpr int tri_index(int e, int f, int nv) {
+    return e * nv - (e * (e - 1)) / 2 + (f - e);
+}
+
+template <typename T, int NV>
+struct Gram {
+    static constexpr int NTRI = NV * (NV + 1) / 2;
+    static constexpr int SLAB_SLOTS = NTRI * 4 + NV;  // x 64 lanes
+    typename Mfma<T>::acc_t acc[NTRI];
+    T b[NV];
+
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t) acc[t] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < NV; ++e) b[e] = T(0);
+    }
+    __device__ __forceinline__ void store(T *slab, int lane) const {
+        int s = 0;
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(s++) * WAVE + lane] = acc[t][r];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) slab[(s++) * WAVE + lane] = b[e];
+    }
+    __device__ __forceinline__ void add(const T *slab, int lane) {
+        int s = 0;
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += slab[(s++) * WAVE + lane];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) b[e] += slab[(s++) * WAVE + lane];
+    }
+};
+
+// One k=4 MFMA step: four neighbours (one per lane group), all upper tiles.
+template <typename T, int NV>
+__device__ __forceinline__ void gram_step(Gram<T, NV> &G, const T (&v)[NV], T rv) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) G.b[e] += rv * v[e];
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = e; f < NV; ++f)
+            G.acc[tri_index(e, f, NV)] = Mfma<T>::mma(v[e], v[f], G.acc[tri_index(e, f, NV)]);
+}
+
+// Accumulate entries [beg, end) of one row.
+template <typename T, int NV>
+__device__ __forceinline__ void gram_range(Gram<T, NV> &G, const int32_t *__restrict__ indices,
+                                           const T *__restrict__ vals,
+                                           const T *__restrict__ src, int64_t beg, int64_t end,
+                                           int lane) {
+    constexpr int KP = NV * 16;
+    const int g = lane >> 4, q = lane & 15;
+    const T *srcq = src + q * NV;
+    for (int64_t base = beg; base < end; base += WAVE) {
+        const int64_t left = end - base;
+        const int cnt = left < WAVE ? (int)left : WAVE;
+        int idx = 0;
+        T rv = T(0);
+        if (lane < cnt) {
+            idx = indices[base + lane];
+            rv = vals[base + lane];
+        }
+        const int nfull = cnt >> 2;
+        int s = 0;
+        for (; s + 4 <= nfull; s += 4) {
+            T v[4][NV];
+            T r4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = 4 * (s + u) + g;
+                const int id = __shfl(idx, sl);
+                r4[u] = __shfl(rv, sl);
+                load_vec<T, NV>(v[u], srcq + (int64_t)id * KP);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gram_step<T, NV>(G, v[u], r4[u]);
+        }
+        for (; s < nfull; ++s) {
+            const int sl = 4 * s + g;
+            const int id = __shfl(idx, sl);
+            const T r1 = __shfl(rv, sl);
+            T v[NV];
+            load_vec<T, NV>(v, srcq + (int64_t)id * KP);
+            gram_step<T, NV>(G, v, r1);
+        }
+        if (cnt & 3) {  // last, partial step: lanes past the end contribute zeros
+            const int sl = 4 * nfull + g;
+            const int id = __shfl(idx, sl);
+            const T r1 = __shfl(rv, sl);
+            T v[NV];
+            load_vec<T, NV>(v, srcq + (int64_t)id * KP);
+            const bool valid = sl < cnt;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) v[e] = valid ? v[e] : T(0);
+            gram_step<T, NV>(G, v, r1);
+        }
+    }
+}
+
+// ---- kernel 1: partial normal equations of the chunks of long rows ---------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void gram_chunks_kernel(
+    const int64_t *__restrict__ ch_beg, const int64_t *__restrict__ ch_end, int n_chunks,
+    const int32_t *__restrict__ indices, const T *__restrict__ vals, const T *__restrict__ src,
+    T *__restrict__ slabs) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= n_chunks) return;
+    Gram<T, NV> G;
+    G.zero();
+    gram_range<T, NV>(G, indices, vals, src, ch_beg[w], ch_end[w], lane);
+    G.store(slabs + (size_t)w * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
+}
+
+// ---- LDS slab geometry ---------------------------------------------------------------------
+template <typename T, int KP>
+struct Slab {
+    static constexpr int PAD = 16 / (int)sizeof(T);
+    static constexpr int LD = KP + PAD;
+    static constexpr int ELEMS = KP * LD + 2 * KP;  // matrix, rhs, 1/diag
+    static constexpr size_t BYTES = (size_t)ELEMS * sizeof(T);
+};
+
+// Accumulator tiles -> symmetric matrix in LDS (natural column order), rhs, ridge.
+template <typename T, int NV>
+__device__ __forceinline__ void assemble(Gram<T, NV> &G, T *Asm, T *bsm, int lane, int rank,
+                                         T ridge) {
+    constexpr int KP = NV * 16;
+    constexpr int LD = Slab<T, KP>::LD;
+    const int g = lane >> 4, q = lane & 15;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        G.b[e] += __shfl_xor(G.b[e], 16);
+        G.b[e] += __shfl_xor(G.b[e], 32);
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = e; f < NV; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = Mfma<T>::crow(g, r) * NV + e;
+                const int j = q * NV + f;
+                const T val = G.acc[tri_index(e, f, NV)][r];
+                Asm[i * LD + j] = val;
+                if (e != f) Asm[j * LD + i] = val;
+            }
+    if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) bsm[q * NV + e] = G.b[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < (KP + 63) / 64; ++rr) {
+        const int row = lane + 64 * rr;
+        if (row < KP) Asm[row * LD + row] += (row < rank) ? ridge : T(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Cholesky + solve with one matrix row per lane held in registers (KP <= 64).
+// Returns false when a pivot is not positive.
+template <typename T, int KP>
+__device__ __forceinline__ bool chol_solve_regs(T *Asm, const T *bsm, int lane, T &x_out) {
+    constexpr int LD = Slab<T, KP>::LD;
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    const int row = lane < KP ? lane : KP - 1;
+    T a[KP];
+#pragma unroll
+    for (int c = 0; c < KP; c += VW) {
+        const vec_t t = *reinterpret_cast<const vec_t *>(Asm + row * LD + c);
+#pragma unroll
+        for (int i = 0; i < VW; ++i) a[c + i] = t[i];
+    }
+    T bb = bsm[row];
+    T y = T(0), rinv = T(1);
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const T d = read_lane(a[p], p);
+        ok = ok && (d > T(0));
+        const T rs = T(1) / sqrt(d);
+        const T yp = read_lane(bb, p) * rs;
+        a[p] *= rs;  // L[row][p]
+        const bool me = lane == p;
+        y = me ? yp : y;
+        rinv = me ? rs : rinv;
+        bb -= a[p] * yp;
+#pragma unroll
+        for (int c = p + 1; c < KP; ++c) {
+            const T lc = read_lane(a[p], c);  // L[c][p]
+            a[c] -= a[p] * lc;
+        }
+    }
+    // L back to LDS, row-major, for the transposed reads of the back substitution
+    if (lane < KP) {
+#pragma unroll
+        for (int c = 0; c < KP; c += VW) {
+            vec_t t;
+#pragma unroll
+            for (int i = 0; i < VW; ++i) t[i] = a[c + i];
+            *reinterpret_cast<vec_t *>(Asm + row * LD + c) = t;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // L^T x = y, column oriented: lane j keeps y_j - sum_{c>p} L[c][j] x_c
+    T x = T(0);
+#pragma unroll 8
+    for (int p = KP - 1; p >= 0; --p) {
+        const T xp = read_lane(y * rinv, p);
+        x = (lane == p) ? xp : x;
+        const T l = Asm[p * LD + row];  // L[p][row]
+        y -= l * xp;
+    }
+    x_out = x;
+    return ok;
+}
+
+// Generic in-LDS Cholesky + solve for any KP (two rows per lane at KP = 128).  Works on the
+// upper triangle stored row-major so that every vector access is contiguous over lanes.
+template <typename T, int KP>
+__device__ __forceinline__ bool chol_solve_lds(T *Asm, T *bsm, T *dsm, int lane, T (&x_out)[(KP + 63) / 64]) {
+    constexpr int LD = Slab<T, KP>::LD;
+    constexpr int R = (KP + 63) / 64;
+    bool ok = true;
+    for (int p = 0; p < KP; ++p) {
+        const T d = Asm[p * LD + p];
+        ok = ok && (d > T(0));
+        const T rs = T(1) / sqrt(d);
+        const T yp = bsm[p] * rs;
+        T lp[R];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int row = lane + 64 * rr;
+            lp[rr] = T(0);
+            if (row >= p && row < KP) {
+                lp[rr] = Asm[p * LD + row] * rs;  // L[row][p], kept at (p,row)
+                Asm[p * LD + row] = lp[rr];
+                if (row == p) {
+                    bsm[p] = yp;
+                    dsm[p] = rs;
+                } else {
+                    bsm[row] -= lp[rr] * yp;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int c = p + 1; c < KP; ++c) {
+            const T lc = Asm[p * LD + c];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int row = lane + 64 * rr;
+                if (row >= c && row < KP) Asm[c * LD + row] -= lp[rr] * lc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int p = KP - 1; p >= 0; --p) {
+        const T xp = bsm[p] * dsm[p];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int row = lane + 64 * rr;
+            if (row == p) bsm[p] = xp;
+            if (row < p) bsm[row] -= Asm[row * LD + p] * xp;  // L[p][row] kept at (row,p)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int row = lane + 64 * rr;
+        x_out[rr] = row < KP ? bsm[row] : T(0);
+    }
+    return ok;
+}
+
+template <typename T>
+struct SolveArgs {
+    const int32_t *order;       // [n_tasks] row ids, longest first
+    const int32_t *slab_first;  // [n_tasks] first workspace slab of the row, -1 = short row
+    const int32_t *slab_count;  // [n_tasks]
+    int n_tasks;
+    const int64_t *indptr;
+    const int32_t *indices;
+    const T *vals;
+    const T *src;
+    const T *slabs;
+    T *dst;
+    int rank;
+    T alpha;
+    // debug dump (normal equations instead of the solve)
+    T *A_out;
+    T *b_out;
+    int64_t row_begin;
+};
+
+// ---- kernel 2: one wave per row — accumulate (or add the row's slabs), assemble, solve -----
+template <typename T, int NV, int WPB, bool DUMP>
+__global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
+    constexpr int KP = NV * 16;
+    constexpr int LD = Slab<T, KP>::LD;
+    constexpr int R = (KP + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    T *Asm = reinterpret_cast<T *>(smem) + (size_t)wl * Slab<T, KP>::ELEMS;
+    T *bsm = Asm + KP * LD;
+    T *dsm = bsm + KP;
+    const int W = gridDim.x * WPB;
+    for (int t = blockIdx.x * WPB + wl; t < p.n_tasks; t += W) {
+        const int row = p.order[t];
+        const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
+        T *out = p.dst + (int64_t)row * KP;
+        if (end <= beg) {
+            if constexpr (DUMP) {
+                T *Ao = p.A_out + (row - p.row_begin) * (int64_t)KP * KP;
+                for (int i = lane; i < KP * KP; i += WAVE) Ao[i] = T(0);
+                for (int i = lane; i < KP; i += WAVE) p.b_out[(row - p.row_begin) * KP + i] = T(0);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+                    if (lane + 64 * rr < KP) out[lane + 64 * rr] = T(0);
+            }
+            continue;
+        }
+        Gram<T, NV> G;
+        G.zero();
+        const int sf = p.slab_first[t];
+        if (sf >= 0) {
+            const int nch = p.slab_count[t];
+            for (int c = 0; c < nch; ++c)
+                G.add(p.slabs + (size_t)(sf + c) * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
+        } else {
+            gram_range<T, NV>(G, p.indices, p.vals, p.src, beg, end, lane);
+        }
+        const T ridge = p.alpha * (T)(end - beg);
+        assemble<T, NV>(G, Asm, bsm, lane, p.rank, ridge);
+        if constexpr (DUMP) {
+            T *Ao = p.A_out + (row - p.row_begin) * (int64_t)KP * KP;
+            for (int i = lane; i < KP * KP; i += WAVE) Ao[i] = Asm[(i / KP) * LD + (i % KP)];
+            for (int i = lane; i < KP; i += WAVE) p.b_out[(row - p.row_begin) * KP + i] = bsm[i];
+        } else if constexpr (KP <= 64) {
+            T x;
+            const bool ok = chol_solve_regs<T, KP>(Asm, bsm, lane, x);
+            if (lane < KP) out[lane] = ok ? x : T(0);
+        } else {
+            T x[R];
+            const bool ok = chol_solve_lds<T, KP>(Asm, bsm, dsm, lane, x);
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+                if (lane + 64 * rr < KP) out[lane + 64 * rr] = ok ? x[rr] : T(0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace alsmi
+
+// ---- plan ------------------------------------------------------------------------------------
+
+struct alsmi_plan {
+    int dtype, rank, kp, chunk, device, cu_count;
+    int64_t n_rows_total, row_begin, row_end;
+    int n_tasks, n_chunks, n_heavy;
+    int32_t *order, *slab_first, *slab_count;
+    int64_t *ch_beg, *ch_end;
+    void *slabs;
+    size_t slab_bytes;
+};
+
+namespace alsmi {
+
+static size_t slab_slots(int kp) {
+    const int nv = kp / 16;
+    return (size_t)(nv * (nv + 1) / 2 * 4 + nv) * WAVE;
+}
+
+template <typename T, int NV, int WPB>
+static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, hipStream_t st) {
+    constexpr int KP = NV * 16;
+    const size_t lds = Slab<T, KP>::BYTES * WPB;
+    int bpc = (int)((160 * 1024) / lds);
+    if (bpc < 1) bpc = 1;
+    if (bpc * WPB > 16) bpc = 16 / WPB;
+    int grid = pl->cu_count * bpc;
+    const int need = (pl->n_tasks + WPB - 1) / WPB;
+    if (grid > need) grid = need;
+    if (grid < 1) return ALSMI_OK;
+    auto kern = dump ? solve_rows_kernel<T, NV, WPB, true> : solve_rows_kernel<T, NV, WPB, false>;
+    ALSMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), lds, st, a);
+    ALSMI_HIP_CHECK(hipGetLastError());
+    return ALSMI_OK;
+}
+
+template <typename T, int NV, int WPB>
+static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
+                          const void *vals, const void *src, void *dst, double alpha, void *A_out,
+                          void *b_out, hipStream_t st) {
+    if (pl->n_chunks > 0) {
+        const int grid = (pl->n_chunks + 3) / 4;
+        hipLaunchKernelGGL((gram_chunks_kernel<T, NV>), dim3(grid), dim3(256), 0, st, pl->ch_beg,
+                           pl->ch_end, pl->n_chunks, indices, static_cast<const T *>(vals),
+                           static_cast<const T *>(src), static_cast<T *>(pl->slabs));
+        ALSMI_HIP_CHECK(hipGetLastError());
+    }
+    SolveArgs<T> a;
+    a.order = pl->order;
+    a.slab_first = pl->slab_first;
+    a.slab_count = pl->slab_count;
+    a.n_tasks = pl->n_tasks;
+    a.indptr = indptr;
+    a.indices = indices;
+    a.vals = static_cast<const T *>(vals);
+    a.src = static_cast<const T *>(src);
+    a.slabs = static_cast<const T *>(pl->slabs);
+    a.dst = static_cast<T *>(dst);
+    a.rank = pl->rank;
+    a.alpha = (T)alpha;
+    a.A_out = static_cast<T *>(A_out);
+    a.b_out = static_cast<T *>(b_out);
+    a.row_begin = pl->row_begin;
+    return launch_solve<T, NV, WPB>(pl, a, A_out != nullptr, st);
+}
+
+static int dispatch(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
+                    const void *vals, const void *src, void *dst, double alpha, void *A_out,
+                    void *b_out, hipStream_t st) {
+#define ALSMI_CASE(T, NV, WPB) \
+    return run_half_sweep<T, NV, WPB>(pl, indptr, indices, vals, src, dst, alpha, A_out, b_out, st)
+    if (pl->dtype == ALSMI_F32) {
+        switch (pl->kp) {
+            case 16: ALSMI_CASE(float, 1, 4);
+            case 32: ALSMI_CASE(float, 2, 4);
+            case 64: ALSMI_CASE(float, 4, 4);
+            case 128: ALSMI_CASE(float, 8, 2);
+        }
+    } else {
+        switch (pl->kp) {
+            case 16: ALSMI_CASE(double, 1, 4);
+            case 32: ALSMI_CASE(double, 2, 4);
+            case 64: ALSMI_CASE(double, 4, 2);
+            case 128: ALSMI_CASE(double, 8, 1);
+        }
+    }
+#undef ALSMI_CASE
+    set_error("unsupported dtype/rank combination");
+    return ALSMI_EINVAL;
+}
+
+}  // namespace alsmi
+
+extern "C" {
+
+int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_rows_total,
+                      int64_t row_begin, int64_t row_end, int rank, int dtype, int chunk) {
+    using namespace alsmi;
+    ALSMI_REQUIRE(out && indptr_host, "alsmi_plan_create: null pointer");
+    ALSMI_REQUIRE(dtype == ALSMI_F32 || dtype == ALSMI_F64, "alsmi_plan_create: bad dtype %d",
+                  dtype);
+    const int kp = alsmi_padded_rank(rank);
+    ALSMI_REQUIRE(kp > 0, "alsmi_plan_create: rank %d outside 1..128", rank);
+    ALSMI_REQUIRE(n_rows_total >= 0 && n_rows_total < INT32_MAX, "alsmi_plan_create: bad row count");
+    ALSMI_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n_rows_total,
+                  "alsmi_plan_create: bad row range [%lld,%lld) of %lld", (long long)row_begin,
+                  (long long)row_end, (long long)n_rows_total);
+    if (chunk <= 0) chunk = 2048;
+    chunk = (chunk + 63) / 64 * 64;
+    const int64_t n = row_end - row_begin;
+    std::vector<int32_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), (int32_t)row_begin);
+    for (int64_t r = row_begin; r < row_end; ++r)
+        ALSMI_REQUIRE(indptr_host[r + 1] >= indptr_host[r] &&
+                          indptr_host[r + 1] - indptr_host[r] < INT32_MAX,
+                      "alsmi_plan_create: indptr not monotone at row %lld", (long long)r);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return indptr_host[a + 1] - indptr_host[a] > indptr_host[b + 1] - indptr_host[b];
+    });
+    std::vector<int32_t> slab_first((size_t)n, -1), slab_count((size_t)n, 0);
+    std::vector<int64_t> ch_beg, ch_end;
+    int n_heavy = 0;
+    for (int64_t t = 0; t < n; ++t) {
+        const int64_t beg = indptr_host[order[t]], end = indptr_host[order[t] + 1];
+        const int64_t deg = end - beg;
+        if (deg <= chunk) break;  // sorted: the rest is short
+        int64_t nch = (deg + chunk - 1) / chunk;
+        int64_t len = ((deg + nch - 1) / nch + 63) / 64 * 64;
+        nch = (deg + len - 1) / len;
+        ALSMI_REQUIRE(ch_beg.size() + (size_t)nch < (size_t)INT32_MAX, "too many chunks");
+        slab_first[t] = (int32_t)ch_beg.size();
+        slab_count[t] = (int32_t)nch;
+        for (int64_t c = 0; c < nch; ++c) {
+            ch_beg.push_back(beg + c * len);
+            ch_end.push_back(std::min(end, beg + (c + 1) * len));
+        }
+        ++n_heavy;
+    }
+    alsmi_plan *pl = new (std::nothrow) alsmi_plan();
+    if (!pl) {
+        set_error("alsmi_plan_create: out of host memory");
+        return ALSMI_ENOMEM;
+    }
+    memset(pl, 0, sizeof(*pl));
+    pl->dtype = dtype;
+    pl->rank = rank;
+    pl->kp = kp;
+    pl->chunk = chunk;
+    pl->n_rows_total = n_rows_total;
+    pl->row_begin = row_begin;
+    pl->row_end = row_end;
+    pl->n_tasks = (int)n;
+    pl->n_chunks = (int)ch_beg.size();
+    pl->n_heavy = n_heavy;
+    pl->cu_count = device_cu_count();
+    const size_t esz = dtype == ALSMI_F32 ? 4 : 8;
+    pl->slab_bytes = (size_t)pl->n_chunks * slab_slots(kp) * esz;
+    hipError_t e = hipGetDevice(&pl->device);
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        *dst = nullptr;
+        if (bytes == 0) return hipSuccess;
+        hipError_t r = hipMalloc(dst, bytes);
+        if (r != hipSuccess) return r;
+        return src ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    if (e == hipSuccess) e = upload((void **)&pl->order, order.data(), (size_t)n * 4);
+    if (e == hipSuccess) e = upload((void **)&pl->slab_first, slab_first.data(), (size_t)n * 4);
+    if (e == hipSuccess) e = upload((void **)&pl->slab_count, slab_count.data(), (size_t)n * 4);
+    if (e == hipSuccess) e = upload((void **)&pl->ch_beg, ch_beg.data(), ch_beg.size() * 8);
+    if (e == hipSuccess) e = upload((void **)&pl->ch_end, ch_end.data(), ch_end.size() * 8);
+    if (e == hipSuccess) e = upload(&pl->slabs, nullptr, pl->slab_bytes);
+    if (e != hipSuccess) {
+        set_error("alsmi_plan_create: device allocation failed: %s", hipGetErrorString(e));
+        alsmi_plan_destroy(pl);
+        return e == hipErrorOutOfMemory ? ALSMI_ENOMEM : ALSMI_EHIP;
+    }
+    *out = pl;
+    return ALSMI_OK;
+}
+
+int alsmi_plan_destroy(alsmi_plan *pl) {
+    if (!pl) return ALSMI_OK;
+    (void)hipFree(pl->order);
+    (void)hipFree(pl->slab_first);
+    (void)hipFree(pl->slab_count);
+    (void)hipFree(pl->ch_beg);
+    (void)hipFree(pl->ch_end);
+    (void)hipFree(pl->slabs);
+    delete pl;
+    return ALSMI_OK;
+}
+
+int alsmi_plan_info(const alsmi_plan *pl, int64_t *n_rows, int64_t *n_heavy_rows,
+                    int64_t *n_chunks, int64_t *workspace_bytes) {
+    ALSMI_REQUIRE(pl, "alsmi_plan_info: null plan");
+    if (n_rows) *n_rows = pl->n_tasks;
+    if (n_heavy_rows) *n_heavy_rows = pl->n_heavy;
+    if (n_chunks) *n_chunks = pl->n_chunks;
+    if (workspace_bytes) *workspace_bytes = (int64_t)pl->slab_bytes;
+    return ALSMI_OK;
+}
+
+static int check_sweep_args(const alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
+                            const void *vals, const void *src, int64_t n_src, const char *who) {
+    ALSMI_REQUIRE(pl, "%s: null plan", who);
+    if (pl->n_tasks == 0) return ALSMI_OK;
+    ALSMI_REQUIRE(indptr && src, "%s: null pointer", who);
+    ALSMI_REQUIRE(n_src >= 1, "%s: the source factor table must have at least one row", who);
+    ALSMI_REQUIRE(indices && vals, "%s: null indices/vals", who);
+    return ALSMI_OK;
+}
+
+int alsmi_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
+                     const void *vals, const void *src_factors, int64_t n_src, void *dst_factors,
+                     double alpha, void *stream) {
+    int rc = check_sweep_args(pl, indptr, indices, vals, src_factors, n_src, "alsmi_half_sweep");
+    if (rc != ALSMI_OK) return rc;
+    if (pl->n_tasks == 0) return ALSMI_OK;
+    ALSMI_REQUIRE(dst_factors, "alsmi_half_sweep: null destination");
+    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, dst_factors, alpha, nullptr,
+                           nullptr, static_cast<hipStream_t>(stream));
+}
+
+int alsmi_normal_equations(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
+                           const void *vals, const void *src_factors, int64_t n_src, void *A_out,
+                           void *b_out, double alpha, void *stream) {
+    int rc = check_sweep_args(pl, indptr, indices, vals, src_factors, n_src,
+                              "alsmi_normal_equations");
+    if (rc != ALSMI_OK) return rc;
+    if (pl->n_tasks == 0) return ALSMI_OK;
+    ALSMI_REQUIRE(A_out && b_out, "alsmi_normal_equations: null output");
+    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, nullptr, alpha, A_out, b_out,
+                           static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// Shared host/device helpers for libalsmi (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/alsmi.h"
+
+namespace alsmi {
+
+void set_error(const char *fmt, ...);
+int device_cu_count();
+
+#define ALSMI_HIP_CHECK(expr)                                                       \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            alsmi::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                             __FILE__, __LINE__);                                   \
+            return ALSMI_EHIP;                                                      \
+        }                                                                           \
+    } while (0)
+
+#define ALSMI_REQUIRE(cond, ...)           \
+    do {                                   \
+        if (!(cond)) {                     \
+            alsmi::set_error(__VA_ARGS__); \
+            return ALSMI_EINVAL;           \
+        }                                  \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+// ---- MFMA 16x16x4 wrappers --------------------------------------------------
+// Operand maps (one element per lane): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15].  The accumulator maps differ between f32 and f64.
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // row of accumulator register r in lane group g (= lane>>4); column = lane&15
+    static __device__ __forceinline__ int crow(int g, int r) { return 4 * g + r; }
+};
+
+template <>
+struct Mfma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int crow(int g, int r) { return g + 4 * r; }
+};
+
+// ---- cross-lane helpers -------------------------------------------------------
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+__device__ __forceinline__ int read_lane(int v, int lane) {
+    return __builtin_amdgcn_readlane(v, lane);
+}
+
+// NV consecutive elements per lane, NV in {1, 2, 4, 8}; p is NV*sizeof(T) aligned.
+template <typename T, int NV>
+__device__ __forceinline__ void load_vec(T (&v)[NV], const T *p) {
+    if constexpr (NV == 1) {
+        v[0] = p[0];
+    } else {
+        typedef T vec_t __attribute__((ext_vector_type(NV)));
+        const vec_t x = *reinterpret_cast<const vec_t *>(p);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) v[e] = x[e];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+}  // namespace alsmi

@@ -1,0 +1,226 @@
+"""HIP ALS path against the oracle and the reference's golden vectors (MI355X)."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from problems import random_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    import torch
+    from alsmi import device as dev
+    return dev.require_gpu(), torch
+
+
+def rel_err(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def col_rel_err(a, b):
+    """largest per-row (per factor vector) relative error; a, b are (rank, n)."""
+    num = np.linalg.norm(a - b, axis=0)
+    den = np.maximum(np.linalg.norm(b, axis=0), 1e-30)
+    return float((num / den).max())
+
+
+CASES = [
+    # seed, n, m, nnz, rank, chunk, extras
+    (1, 40, 30, 300, 2, 0, {}),
+    (2, 60, 50, 900, 10, 0, dict(empty_rows=(0, 7, 59), empty_cols=(3,))),
+    (3, 50, 300, 2500, 20, 64, dict(long_row=(5, 290))),
+    (4, 80, 400, 3000, 64, 128, dict(long_row=(11, 390), empty_rows=(2,))),
+    (5, 30, 200, 1500, 100, 64, dict(long_row=(3, 170))),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'k%d' % c[4])
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_normal_equations_and_half_sweep(gpu, case, dtype):
+    device, torch = gpu
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    seed, n, m, nnz, rank, chunk, extra = case
+    P = random_problem(seed, n, m, nnz, rank, **extra)
+    alpha = 0.1
+    side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], n, m, dtype, device)
+    plan = dev.SweepPlan(side, rank, chunk=chunk)
+    if chunk:
+        assert plan.info()['n_chunks'] > 1
+    V = dev.factors_to_device(P['V'], dtype, device)
+    Vq = dev.factors_to_host(V, rank)  # the table as the device sees it (fp32-rounded)
+    kp = dev.padded_rank(rank)
+    A, b = plan.normal_equations(V, alpha)
+    A, b = A.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+    tol = 1e-12 if dtype == 'float64' else 2e-6
+    for r in range(n):
+        lo, hi = P['indptr'][r], P['indptr'][r + 1]
+        S = Vq[:, P['indices'][lo:hi]]
+        if hi == lo:
+            assert not A[r].any() and not b[r].any()
+            continue
+        Aref = np.zeros((kp, kp))
+        Aref[:rank, :rank] = S.dot(S.T) + alpha * (hi - lo) * np.eye(rank)
+        Aref[rank:, rank:] = np.eye(kp - rank)
+        bref = np.zeros(kp)
+        bref[:rank] = S.dot(P['vals'][lo:hi])
+        assert rel_err(A[r], Aref) < tol, r
+        assert rel_err(b[r], bref) < tol, r
+    U = torch.full((n, kp), 7.0, dtype=V.dtype, device=device)
+    plan.half_sweep(V, U, alpha)
+    got = dev.factors_to_host(U, rank)
+    assert not U[:, rank:].any()
+    want = ao.half_sweep(P['indptr'], P['indices'], P['vals'], Vq, rank, alpha)
+    # north-star bar: 1e-10 relative in fp64, 1e-4 in fp32
+    assert col_rel_err(got, want) < (1e-10 if dtype == 'float64' else 1e-4)
+    for r in (0, 2, 7, 59):
+        if r < n and P['indptr'][r] == P['indptr'][r + 1]:
+            assert not got[:, r].any()
+    plan.close()
+
+
+def test_half_sweep_singular_gives_zeros(gpu):
+    """A = 0 (zero source factors, alpha = 0): the reference's inv() raises
+    LinAlgError and the row becomes zeros (src/als.py:246-249)."""
+    device, torch = gpu
+    from alsmi import device as dev
+    for dtype, rank in (('float64', 20), ('float32', 64), ('float64', 100)):
+        P = random_problem(9, 6, 40, 60, rank)
+        side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], 6, 40, dtype, device)
+        plan = dev.SweepPlan(side, rank)
+        V = dev.factors_to_device(np.zeros_like(P['V']), dtype, device)
+        U = torch.ones((6, dev.padded_rank(rank)), dtype=V.dtype, device=device)
+        plan.half_sweep(V, U, 0.0)
+        assert not U.cpu().numpy().any()
+        plan.close()
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+@pytest.mark.parametrize('rank', [3, 10, 64, 128])
+def test_sddmm_matches_oracle(gpu, dtype, rank):
+    device, torch = gpu
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    P = random_problem(20 + rank, 70, 90, 1531, rank)
+    U = dev.factors_to_device(P['U'], dtype, device)
+    V = dev.factors_to_device(P['V'], dtype, device)
+    Uq, Vq = dev.factors_to_host(U, rank), dev.factors_to_host(V, rank)
+    users = torch.from_numpy(P['users']).to(device)
+    items = torch.from_numpy(P['items']).to(device)
+    vals = torch.from_numpy(P['vals'].astype(dtype)).to(device)
+    pred, sse = dev.sddmm(rank, users, items, U, V, vals)
+    want = ao.predict_pairs(Uq, Vq, P['users'], P['items'])
+    tol = 1e-13 if dtype == 'float64' else 2e-6
+    np.testing.assert_allclose(pred.cpu().numpy(), want, rtol=tol, atol=tol)
+    np.testing.assert_allclose(float(sse.cpu()[0]), np.sum((P['vals'] - want) ** 2),
+                               rtol=1e-12 if dtype == 'float64' else 1e-5)
+    # prediction only, and the empty call
+    pred2, none = dev.sddmm(rank, users[:5], items[:5], U, V)
+    assert none is None and torch.equal(pred2, pred[:5])
+    e = torch.empty(0, dtype=torch.int32, device=device)
+    pred3, sse3 = dev.sddmm(rank, e, e, U, V, vals[:0])
+    assert pred3.numel() == 0 and float(sse3.cpu()[0]) == 0.0
+
+
+def test_expand_rows(gpu):
+    device, torch = gpu
+    from alsmi import device as dev
+    P = random_problem(31, 50, 40, 700, 4, empty_rows=(0, 10, 49))
+    side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], 50, 40, 'float64', device)
+    assert np.array_equal(side.expand_rows().cpu().numpy(), P['users'])
+    lo, hi = P['indptr'][10], P['indptr'][30]
+    assert np.array_equal(side.expand_rows(10, 30).cpu().numpy(), P['users'][lo:hi])
+
+
+def test_als_unit_known_answers(gpu, golden):
+    """reference tests/test_als.py: fit, fit_transform, predict*, score, add_user."""
+    from alsmi import ALS
+    R = sps.csr_matrix(np.array([[3, 0, 4], [4, 5, 0]]))
+    users, items = R.nonzero()
+    als = ALS(2, tol=0.000001, random_state=42)
+    u, i = als.fit_transform((users, items), R)
+    expected_u = np.array([[1.52198247, 1.97980245], [-0.79543119, -1.03470076]])
+    expected_i = np.array([[1.5339228, 1.94471076, 1.99660463],
+                           [-0.80167146, -1.01636085, -1.04348219]])
+    np.testing.assert_allclose(expected_u, u, rtol=1e-7)
+    np.testing.assert_allclose(expected_i, i, rtol=1e-7)
+    g = golden('als_unit')
+    np.testing.assert_allclose(u, g['user_feats'], rtol=1e-9)
+    np.testing.assert_allclose(i, g['item_feats'], rtol=1e-9)
+    assert 2 * als.n_iter_ == int(g['half_sweeps'])
+    np.testing.assert_allclose(als.reconstruction_err_, -0.10663924910933506, rtol=1e-9)
+    with pytest.raises(ValueError) as ctx:
+        als.fit_transform((users, items), R.data)
+    assert str(ctx.value) == 'When y is a scalar or 1-D array shape must be' + 'provided.'
+    u2, i2 = als.fit_transform((users, items), R.data, shape=R.shape)
+    np.testing.assert_allclose(expected_u, u2, rtol=1e-7)
+    np.testing.assert_allclose(expected_i, i2, rtol=1e-7)
+    np.testing.assert_allclose(als._predict((users, items)),
+                               [2.9722781, 3.86881553, 3.86635418, 4.90177248], rtol=1e-7)
+    one = als.predict_one(0, 1)
+    assert one.shape == (1,)
+    np.testing.assert_allclose(one, 3.768260826602256, rtol=1e-9)
+    np.testing.assert_allclose(als.predict_all(0), [2.972278, 3.76826083, 3.86881553], rtol=1e-7)
+    np.testing.assert_allclose(als.score((users, items), R.data), -0.10663924910933506, rtol=1e-9)
+    np.testing.assert_allclose(als.score((users, items), R), -0.10663924910933506, rtol=1e-9)
+    # update_user: expected matrix of reference tests/test_als.py:122-124
+    als.update_user(0, 1, 5)
+    np.testing.assert_allclose(als.user_feats, [[1.69210752, 1.97980245],
+                                                [-0.8843431, -1.03470076]], rtol=1e-7)
+    als.add_user()
+    assert als.data.shape[0] == 3 and als.user_feats.shape[1] == 3
+
+
+@pytest.mark.parametrize('name', ['als_c1', 'als_k64', 'als_k3'])
+def test_als_sweeps_match_reference_fp64(gpu, golden, name):
+    from alsmi import ALS
+    g = golden(name)
+    n, m = (int(v) for v in g['shape'])
+    keep = [int(s) for s in g['keep']]
+    for s in keep:
+        als = ALS(rank=int(g['rank']), alpha=float(g['alpha']), random_state=int(g['seed']),
+                  max_iter=s)
+        u, i = als.fit_transform((g['users'], g['items']), g['vals'], shape=(n, m))
+        assert col_rel_err(u, g['user_feats_%d' % s]) < 1e-9
+        assert col_rel_err(i, g['item_feats_%d' % s]) < 1e-9
+        np.testing.assert_allclose(als.rmse_history_, g['rmse'][:s], rtol=1e-11)
+    np.testing.assert_allclose(als._predict((g['pair_users'], g['pair_items'])), g['pair_pred'],
+                               rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(als.score((g['users'], g['items']), g['vals']),
+                               g['score_train'], rtol=1e-9)
+    # index structure is bit-exact
+    ref = sps.csr_matrix((g['vals'], (g['users'], g['items'])), shape=(n, m))
+    assert np.array_equal(als.data.indptr, ref.indptr)
+    assert np.array_equal(als.data.indices, ref.indices)
+    assert np.array_equal(als.data.data, ref.data)
+
+
+def test_als_c1_fp32(gpu, golden):
+    """BASELINE config 1 in the fp32 throughput mode: RMSE within 1e-5 relative
+    per sweep, factors after the first half-sweeps within 1e-4."""
+    from alsmi import ALS
+    g = golden('als_c1')
+    n, m = (int(v) for v in g['shape'])
+    als = ALS(rank=10, alpha=0.1, random_state=42, max_iter=1, dtype='float32')
+    u, i = als.fit_transform((g['users'], g['items']), g['vals'], shape=(n, m))
+    assert col_rel_err(u, g['user_feats_1']) < 1e-4
+    assert col_rel_err(i, g['item_feats_1']) < 1e-4
+    als = ALS(rank=10, alpha=0.1, random_state=42, max_iter=10, dtype='float32')
+    als.fit((g['users'], g['items']), g['vals'], shape=(n, m))
+    np.testing.assert_allclose(als.rmse_history_, g['rmse'], rtol=1e-5)
+
+
+def test_als_tol_loop(gpu, golden):
+    from alsmi import ALS
+    g = golden('als_fit_tol')
+    n, m = (int(v) for v in g['shape'])
+    als = ALS(rank=5, alpha=0.1, tol=0.001, random_state=3)
+    u, i = als.fit_transform((g['users'], g['items']), g['vals'], shape=(n, m))
+    assert 2 * als.n_iter_ == int(g['half_sweeps_dense'])
+    np.testing.assert_allclose(u, g['user_feats_dense'], rtol=1e-8)
+    np.testing.assert_allclose(als.reconstruction_err_, g['err_dense'], rtol=1e-10)
+    R = sps.csr_matrix((g['vals'], (g['users'], g['items'])), shape=(n, m))
+    als2 = ALS(rank=5, alpha=0.1, tol=0.001, random_state=3).fit((g['users'], g['items']), R)
+    np.testing.assert_allclose(als2.item_feats, g['item_feats_sparse'], rtol=1e-8)
