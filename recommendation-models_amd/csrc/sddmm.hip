@@ -162,7 +162,7 @@ int alsmi_sddmm(int dtype, int rank, int64_t n_pairs, const int32_t *users, cons
     ALSMI_REQUIRE(kp > 0, "alsmi_sddmm: rank %d outside 1..128", rank);
     ALSMI_REQUIRE(n_pairs >= 0, "alsmi_sddmm: negative pair count");
     ALSMI_REQUIRE(workspace, "alsmi_sddmm: null workspace");
-    ALSMI_REQUIRE(!sse_out || vals, "alsmi_sddmm: sse_out needs vals");
+    ALSMI_REQUIRE(!sse_out || vals || n_pairs == 0, "alsmi_sddmm: sse_out needs vals");
     if (n_pairs > 0)
         ALSMI_REQUIRE(users && items && row_factors && col_factors, "alsmi_sddmm: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
