@@ -102,8 +102,8 @@ class ALS(BaseEstimator):
         self.user_feats = np.zeros((self.rank, n))
         self.data = data
 
-        engine = AlsEngine(data.indptr, data.indices, data.data, (n, m), self.rank, self.alpha,
-                           dtype=self.dtype, group=_default_group())
+        engine = AlsEngine.from_global(data.indptr, data.indices, data.data, (n, m), self.rank,
+                                       self.alpha, dtype=self.dtype, group=_default_group())
         engine.set_factors(self.user_feats, self.item_feats)
         rmse = float('inf')
         diff = rmse

@@ -53,26 +53,34 @@ def factors_to_host(table, rank):
     return np.ascontiguousarray(table[:, :rank].to(torch.float64).cpu().numpy().T)
 
 
+def _as_device(a, tdtype, device):
+    if torch.is_tensor(a):
+        return a.to(device=device, dtype=tdtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=tdtype)
+
+
 class SparseSide(object):
     """One orientation of the ratings on the device: CSR for the user side,
     CSC (as the CSR of the transpose) for the item side."""
 
     def __init__(self, indptr, indices, vals, n_rows, n_cols, dtype, device):
+        """indptr/indices/vals may be numpy arrays (uploaded) or torch tensors."""
+        if torch.is_tensor(indptr):
+            indptr = indptr.cpu().numpy()
         indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         if indptr.shape != (n_rows + 1,):
             raise ValueError('indptr must have n_rows + 1 entries')
         nnz = int(indptr[-1])
         if len(indices) != nnz or len(vals) != nnz:
             raise ValueError('indices/vals do not match indptr')
-        indices = np.asarray(indices)
-        if nnz and (indices.min() < 0 or indices.max() >= n_cols):
-            raise ValueError('column index out of range')
         self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), nnz
         self.dtype = np.dtype(dtype)
         self.indptr_host = indptr
         self.indptr = torch.from_numpy(indptr).to(device)
-        self.indices = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).to(device)
-        self.vals = torch.from_numpy(np.ascontiguousarray(vals, dtype=self.dtype)).to(device)
+        self.indices = _as_device(indices, torch.int32, device)
+        self.vals = _as_device(vals, torch_dtype(self.dtype), device)
+        if nnz and (int(self.indices.min()) < 0 or int(self.indices.max()) >= n_cols):
+            raise ValueError('column index out of range')
         self.device = device
 
     def expand_rows(self, row_begin=0, row_end=None):

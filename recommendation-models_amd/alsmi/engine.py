@@ -50,8 +50,13 @@ class LocalBackend(object):
 
 
 class AlsEngine(object):
-    def __init__(self, indptr, indices, vals, shape, rank, alpha, dtype=np.float64,
-                 group=None, backend=None, chunk=0, csc=None):
+    """csr / csc are this rank's LOCAL slices: (indptr, indices, vals) of its user
+    rows (columns = global item ids) and of its item rows (columns = global user
+    ids), numpy arrays or device tensors.  user_bounds / item_bounds give every
+    rank's row range (world+1 entries each); None means a single rank."""
+
+    def __init__(self, csr, csc, shape, rank, alpha, dtype=np.float64, user_bounds=None,
+                 item_bounds=None, group=None, backend=None, chunk=0, total_nnz=None):
         self.backend = backend if backend is not None else LocalBackend()
         self.n, self.m = int(shape[0]), int(shape[1])
         self.rank, self.alpha = int(rank), float(alpha)
@@ -63,26 +68,17 @@ class AlsEngine(object):
             self.me = dist.get_rank(group)
         else:
             self.world, self.me = 1, 0
-        indptr = np.asarray(indptr, dtype=np.int64)
-        self.nnz = int(indptr[-1])
-        if csc is None:
-            mat = sps.csr_matrix((np.asarray(vals), np.asarray(indices), indptr),
-                                 shape=(self.n, self.m)).tocsc()
-            mat.sort_indices()
-            csc = (mat.indptr.astype(np.int64), mat.indices, mat.data)
-        cptr, cidx, cvals = csc
-        self.user_bounds = split_by_nnz(indptr, self.world)
-        self.item_bounds = split_by_nnz(cptr, self.world)
-        ulo, uhi = int(self.user_bounds[self.me]), int(self.user_bounds[self.me + 1])
-        ilo, ihi = int(self.item_bounds[self.me]), int(self.item_bounds[self.me + 1])
-        self.ulo, self.uhi, self.ilo, self.ihi = ulo, uhi, ilo, ihi
+        self.user_bounds = np.asarray([0, self.n] if user_bounds is None else user_bounds,
+                                      dtype=np.int64)
+        self.item_bounds = np.asarray([0, self.m] if item_bounds is None else item_bounds,
+                                      dtype=np.int64)
+        if self.user_bounds.size != self.world + 1 or self.item_bounds.size != self.world + 1:
+            raise ValueError('row bounds must have world_size + 1 entries')
+        self.ulo, self.uhi = (int(v) for v in self.user_bounds[self.me:self.me + 2])
+        self.ilo, self.ihi = (int(v) for v in self.item_bounds[self.me:self.me + 2])
         b = self.backend
-        a, z = int(indptr[ulo]), int(indptr[uhi])
-        self.csr = b.make_side(indptr[ulo:uhi + 1] - a, indices[a:z], vals[a:z], uhi - ulo,
-                               self.m, self.dtype)
-        a, z = int(cptr[ilo]), int(cptr[ihi])
-        self.csc = b.make_side(cptr[ilo:ihi + 1] - a, cidx[a:z], cvals[a:z], ihi - ilo, self.n,
-                               self.dtype)
+        self.csr = b.make_side(csr[0], csr[1], csr[2], self.uhi - self.ulo, self.m, self.dtype)
+        self.csc = b.make_side(csc[0], csc[1], csc[2], self.ihi - self.ilo, self.n, self.dtype)
         self.plan_u = b.make_plan(self.csr, self.rank, chunk)
         self.plan_i = b.make_plan(self.csc, self.rank, chunk)
         self.kp = b.padded_rank(self.rank)
@@ -90,6 +86,39 @@ class AlsEngine(object):
         self.V = b.zeros(self.m, self.kp, self.dtype)
         self.pair_rows = self.csr.expand_rows()  # local row ids of this rank's entries
         self.local_nnz = self.csr.nnz
+        if total_nnz is None:
+            total_nnz = self.local_nnz
+            if self.world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([float(self.local_nnz)], dtype=torch.float64,
+                                 device=self.U.device)
+                dist.all_reduce(t, group=group)
+                total_nnz = int(t.cpu()[0])
+        self.nnz = int(total_nnz)
+
+    @classmethod
+    def from_global(cls, indptr, indices, vals, shape, rank, alpha, dtype=np.float64,
+                    group=None, backend=None, chunk=0):
+        """Every rank holds the whole CSR on the host; cut it into per-rank ranges
+        balanced by stored entries and keep the local slices."""
+        n, m = int(shape[0]), int(shape[1])
+        if group is not None:
+            import torch.distributed as dist
+            world, me = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            world, me = 1, 0
+        indptr = np.asarray(indptr, dtype=np.int64)
+        mat = sps.csr_matrix((np.asarray(vals), np.asarray(indices), indptr),
+                             shape=(n, m)).tocsc()
+        mat.sort_indices()
+        cptr, cidx, cvals = mat.indptr.astype(np.int64), mat.indices, mat.data
+        ub, ib = split_by_nnz(indptr, world), split_by_nnz(cptr, world)
+        a, z = int(indptr[ub[me]]), int(indptr[ub[me + 1]])
+        csr = (indptr[ub[me]:ub[me + 1] + 1] - a, indices[a:z], vals[a:z])
+        a, z = int(cptr[ib[me]]), int(cptr[ib[me + 1]])
+        csc = (cptr[ib[me]:ib[me + 1] + 1] - a, cidx[a:z], cvals[a:z])
+        return cls(csr, csc, (n, m), rank, alpha, dtype=dtype, user_bounds=ub, item_bounds=ib,
+                   group=group, backend=backend, chunk=chunk, total_nnz=int(indptr[-1]))
 
     # ---- factors ------------------------------------------------------------
     def set_factors(self, user_feats, item_feats):
