@@ -14,7 +14,7 @@
 //   matrix is therefore mfma(v[e], v[f]) with no LDS staging and no transpose; only the
 //   NV(NV+1)/2 tiles with e <= f are computed.
 //   The accumulators go through a wave-private LDS slab once (tile layout -> one matrix row
-//   per lane), the Cholesky factorisation, the forward substitution (fused) and the back
+//   per lane), the LDL^T factorisation, the forward substitution (fused) and the back
 //   substitution run inside the wave with v_readlane broadcasts — no barrier, no host round
 //   trip.
 //   Rows longer than `chunk` entries are cut into chunks; a first kernel writes each chunk's
@@ -195,10 +195,53 @@ __device__ __forceinline__ void assemble(Gram<T, NV> &G, T *Asm, T *bsm, int lan
     __builtin_amdgcn_wave_barrier();
 }
 
-// Cholesky + solve with one matrix row per lane held in registers (KP <= 64).
-// Returns false when a pivot is not positive.
+// 1/d for a positive pivot.  fp32: hardware reciprocal plus one Newton step (full fp32
+// accuracy, no division sequence on the critical path); fp64: a true division.
+__device__ __forceinline__ float pivot_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(r, fmaf(-d, r, 1.0f), r);
+}
+__device__ __forceinline__ double pivot_rcp(double d) { return 1.0 / d; }
+
+// One elimination step of the in-register LDL^T, P known at compile time so that every
+// register index is static (a runtime-indexed row would be demoted to scratch memory).
+template <typename T, int KP, int P>
+struct LdlStep {
+    static __device__ __forceinline__ void run(T (&a)[KP], T &bb, T &w, int &bad, int lane) {
+        constexpr int BATCH = 8;
+        const T u = a[P];  // column P of the current Schur complement, one element per lane
+        const T d = read_lane(u, P);
+        bad |= (d > T(0)) ? 0 : 1;
+        const T inv = pivot_rcp(d);
+        const T zp = read_lane(bb, P);
+        const T l = u * inv;  // L[row][P]
+        a[P] = l;
+        w = (lane == P) ? zp * inv : w;
+        bb -= l * zp;
+#pragma unroll
+        for (int c0 = P + 1; c0 < KP; c0 += BATCH) {
+            T sc[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i)
+                if (c0 + i < KP) sc[i] = read_lane(u, c0 + i);  // A[c][P]
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i)
+                if (c0 + i < KP) a[c0 + i] -= l * sc[i];
+        }
+        LdlStep<T, KP, P + 1>::run(a, bb, w, bad, lane);
+    }
+};
 template <typename T, int KP>
-__device__ __forceinline__ bool chol_solve_regs(T *Asm, const T *bsm, int lane, T &x_out) {
+struct LdlStep<T, KP, KP> {
+    static __device__ __forceinline__ void run(T (&)[KP], T &, T &, int &, int) {}
+};
+
+// LDL^T factorisation + solve with one matrix row per lane held in registers (KP <= 64).
+// A = L D L^T with unit lower-triangular L needs no square roots; the forward substitution
+// is fused into the factorisation.  Returns false when a pivot is not positive (the matrix
+// is not positive definite).
+template <typename T, int KP>
+__device__ __forceinline__ bool ldl_solve_regs(T *Asm, const T *bsm, int lane, T &x_out) {
     constexpr int LD = Slab<T, KP>::LD;
     constexpr int VW = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VW)));
@@ -211,25 +254,9 @@ __device__ __forceinline__ bool chol_solve_regs(T *Asm, const T *bsm, int lane, 
         for (int i = 0; i < VW; ++i) a[c + i] = t[i];
     }
     T bb = bsm[row];
-    T y = T(0), rinv = T(1);
-    bool ok = true;
-#pragma unroll
-    for (int p = 0; p < KP; ++p) {
-        const T d = read_lane(a[p], p);
-        ok = ok && (d > T(0));
-        const T rs = T(1) / sqrt(d);
-        const T yp = read_lane(bb, p) * rs;
-        a[p] *= rs;  // L[row][p]
-        const bool me = lane == p;
-        y = me ? yp : y;
-        rinv = me ? rs : rinv;
-        bb -= a[p] * yp;
-#pragma unroll
-        for (int c = p + 1; c < KP; ++c) {
-            const T lc = read_lane(a[p], c);  // L[c][p]
-            a[c] -= a[p] * lc;
-        }
-    }
+    T w = T(0);   // lane p ends with z_p / d_p
+    int bad = 0;  // bitwise, so that no step is skipped through an early-out branch
+    LdlStep<T, KP, 0>::run(a, bb, w, bad, lane);
     // L back to LDS, row-major, for the transposed reads of the back substitution
     if (lane < KP) {
 #pragma unroll
@@ -242,17 +269,17 @@ __device__ __forceinline__ bool chol_solve_regs(T *Asm, const T *bsm, int lane, 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // L^T x = y, column oriented: lane j keeps y_j - sum_{c>p} L[c][j] x_c
+    // L^T x = w, column oriented: lane j keeps w_j - sum_{c>p} L[c][j] x_c
     T x = T(0);
 #pragma unroll 8
     for (int p = KP - 1; p >= 0; --p) {
-        const T xp = read_lane(y * rinv, p);
+        const T xp = read_lane(w, p);
         x = (lane == p) ? xp : x;
         const T l = Asm[p * LD + row];  // L[p][row]
-        y -= l * xp;
+        w -= l * xp;
     }
     x_out = x;
-    return ok;
+    return bad == 0;
 }
 
 // Generic in-LDS Cholesky + solve for any KP (two rows per lane at KP = 128).  Works on the
@@ -384,7 +411,7 @@ __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
             for (int i = lane; i < KP; i += WAVE) p.b_out[(row - p.row_begin) * KP + i] = bsm[i];
         } else if constexpr (KP <= 64) {
             T x;
-            const bool ok = chol_solve_regs<T, KP>(Asm, bsm, lane, x);
+            const bool ok = ldl_solve_regs<T, KP>(Asm, bsm, lane, x);
             if (lane < KP) out[lane] = ok ? x : T(0);
         } else {
             T x[R];
