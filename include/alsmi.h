@@ -107,6 +107,32 @@ int alsmi_sddmm(int dtype, int rank, int64_t n_pairs, const int32_t *users,
 int alsmi_expand_rows(const int64_t *indptr, int64_t row_begin, int64_t row_end,
                       int32_t *rows_out, void *stream);
 
+/* ---- IMC objective pieces: src/imc.py:43-48 (_cost), :65-71 (_cost_prime),
+ * :91-96 (_cost_hess), :157 (initial Z) ------------------------------------
+ *
+ * The reference works on one dense feature row per SAMPLE.  Here the samples
+ * are index pairs grouped by user: `indptr` [n_users+1] and `items` [n_s] are
+ * the CSR structure of the ratings, `ratings` [n_s] their values in that order;
+ * X [n_users x p] and M [p x q] are plain row-major; Y is [n_items x ldy] with
+ * ldy = alsmi_imc_padded_width(q) and zero pad columns.  With A = X M and
+ * d_e = <A[u_e], Y[i_e]>:
+ *   mode 0: out = X^T diag-weighted-sum (d_e - r_e) Y[i_e]   (the data part of the
+ *           gradient), sse_out[0] = sum_e (r_e - d_e)^2       (the data part of the cost)
+ *   mode 1: out = X^T sum d_e Y[i_e]                          (the data part of H*M)
+ * `out` [p x q] row-major, `pred_out` [n_s] (the d_e, in the order of `items`) and
+ * `sse_out` may each be NULL when not wanted.  The caller
+ * adds the reference's regulariser terms, which are O(p q): 0.5*n_s*lam*||Z||^2 to
+ * the cost (the reference counts it once per sample), lam*Z to the gradient and
+ * the scalar lam to every entry of the Hessian-vector product.
+ * Calling mode 0 with M = 0 and negated ratings gives X^T diag(r) Y of
+ * src/imc.py:157.  1 <= q <= 256. */
+int alsmi_imc_padded_width(int q);
+size_t alsmi_imc_workspace_bytes(int dtype, int64_t n_users, int p, int q);
+int alsmi_imc_eval(int dtype, int mode, int64_t n_users, int p, int q, const int64_t *indptr,
+                   const int32_t *items, const void *ratings, const void *X, const void *Y,
+                   const void *M, void *out, void *pred_out, double *sse_out, void *workspace,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,8 @@ through ctypes.  Importing the package does not need a GPU; using an estimator
 does, and there is no CPU fallback.
 """
 from .als import ALS
+from .dimc import DirtyIMC
+from .imc import IMC
 from .utils import DataHolder
 
-__all__ = ['ALS', 'DataHolder']
+__all__ = ['ALS', 'IMC', 'DirtyIMC', 'DataHolder']

@@ -1,0 +1,303 @@
+"""Inductive matrix completion (R ~ X Z Y^T) on MI355X.
+
+Same surface as the reference's ``src/imc.py``: module functions ``_cost``,
+``_cost_prime``, ``_cost_hess`` with the scipy.optimize callback signature
+``args = (users, items, ratings, lam, shape)``, ``_fit_imc`` and the ``IMC``
+estimator.  The optimiser loop stays scipy's (so iterates follow the reference);
+every function / gradient / Hessian-vector evaluation is one pass of libalsmi's
+SDDMM + SpMM + GEMM kernels over the samples.
+
+Two input forms are accepted wherever the reference takes ``(X, y)``:
+  * per-sample (what the current reference accepts, src/imc.py:241-242):
+    ``X = (x, y_)`` with one feature row per sample and ``y`` the 1-D ratings;
+  * attribute form (what the reference's tests/test_imc.py:127-210 and
+    tests/test_utils.py:80-94 specify): ``X = (X_attrs, Y_attrs)`` with one row
+    per user / item and ``y`` a sparse ratings matrix.  Nothing is expanded to
+    per-sample rows on the device.
+"""
+import numbers
+import warnings
+
+import numpy as np
+import scipy.optimize as so
+from scipy.sparse import issparse
+from sklearn.base import BaseEstimator
+from sklearn.exceptions import ConvergenceWarning
+from sklearn.utils.validation import check_is_fitted
+
+from . import _lib
+from . import device as dev
+from .utils import _check_x, root_mean_squared_error
+
+INTEGER_TYPES = (numbers.Integral, np.integer)
+
+
+class ImcProblem(object):
+    """Device-resident IMC data in index form and the three evaluations on it."""
+
+    def __init__(self, X_attrs, Y_attrs, users, items, ratings, dtype=np.float64):
+        import torch
+        self.device = dev.require_gpu()
+        self.dtype = np.dtype(dtype)
+        lib = _lib.load()
+        X_attrs = np.atleast_2d(np.asarray(X_attrs, dtype=np.float64))
+        Y_attrs = np.atleast_2d(np.asarray(Y_attrs, dtype=np.float64))
+        users = np.asarray(users).ravel().astype(np.int64)
+        items = np.asarray(items).ravel().astype(np.int64)
+        ratings = np.asarray(ratings, dtype=np.float64).ravel()
+        if not (users.size == items.size == ratings.size):
+            raise ValueError('users, items and ratings must have the same length')
+        self.n_users, self.p = X_attrs.shape
+        self.n_items, self.q = Y_attrs.shape
+        if users.size and (users.min() < 0 or users.max() >= self.n_users or
+                           items.min() < 0 or items.max() >= self.n_items):
+            raise IndexError('sample index out of range')
+        self.ld = lib.alsmi_imc_padded_width(self.q)
+        if self.ld == 0:
+            raise ValueError('item attribute count must be between 1 and 256, got %d' % self.q)
+        self.n_samples = int(users.size)
+        # group the samples by user; `order` maps grouped position -> caller position
+        self.order = np.argsort(users, kind='stable')
+        indptr = np.zeros(self.n_users + 1, dtype=np.int64)
+        np.cumsum(np.bincount(users, minlength=self.n_users), out=indptr[1:])
+        td = dev.torch_dtype(self.dtype)
+        to = lambda a, t: torch.from_numpy(np.ascontiguousarray(a)).to(self.device, t)
+        self.indptr = to(indptr, torch.int64)
+        self.items = to(items[self.order].astype(np.int32), torch.int32)
+        self.ratings = to(ratings[self.order], td)
+        self.X = to(X_attrs, td)
+        ypad = np.zeros((self.n_items, self.ld))
+        ypad[:, :self.q] = Y_attrs
+        self.Y = to(ypad, td)
+        nbytes = int(lib.alsmi_imc_workspace_bytes(_lib.dtype_code(self.dtype), self.n_users,
+                                                   self.p, self.q))
+        self.workspace = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self.device)
+        self._torch = torch
+        self._td = td
+
+    def _eval(self, mode, M, want_out=True, want_sse=False, want_pred=False, ratings=None):
+        torch = self._torch
+        M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(self.p, self.q))
+        Md = torch.from_numpy(M).to(self.device, self._td)
+        out = torch.empty((self.p, self.q), dtype=self._td, device=self.device) \
+            if want_out else None
+        sse = torch.zeros(1, dtype=torch.float64, device=self.device) if want_sse else None
+        pred = torch.empty(self.n_samples, dtype=self._td, device=self.device) \
+            if want_pred else None
+        r = self.ratings if ratings is None else ratings
+        if self.n_users == 0 or self.n_samples == 0:
+            zero = np.zeros((self.p, self.q))
+            return (zero if want_out else None, 0.0 if want_sse else None,
+                    np.zeros(0) if want_pred else None)
+        _lib.check(_lib.load().alsmi_imc_eval(
+            _lib.dtype_code(self.dtype), int(mode), self.n_users, self.p, self.q,
+            dev._ptr(self.indptr), dev._ptr(self.items), dev._ptr(r), dev._ptr(self.X),
+            dev._ptr(self.Y), dev._ptr(Md), dev._ptr(out), dev._ptr(pred), dev._ptr(sse),
+            dev._ptr(self.workspace), dev._stream()), 'alsmi_imc_eval')
+        out_h = out.to(torch.float64).cpu().numpy() if want_out else None
+        sse_h = float(sse.cpu()[0]) if want_sse else None
+        pred_h = None
+        if want_pred:
+            grouped = pred.to(torch.float64).cpu().numpy()
+            pred_h = np.empty_like(grouped)
+            pred_h[self.order] = grouped
+        return out_h, sse_h, pred_h
+
+    # the three callbacks, with the reference's regulariser terms added on the host
+    def cost(self, Z, lam):
+        """src/imc.py:43-48, including its quirk: lam*||Z||^2 is inside the sum
+        over samples, i.e. counted n_samples times."""
+        Z = np.asarray(Z, dtype=np.float64)
+        _, sse, _ = self._eval(0, Z, want_out=False, want_sse=True)
+        return 0.5 * (sse + self.n_samples * lam * np.linalg.norm(Z) ** 2)
+
+    def grad(self, Z, lam):
+        """src/imc.py:65-71: X^T diag(preds - r) Y + lam Z."""
+        Z = np.asarray(Z, dtype=np.float64).reshape(self.p, self.q)
+        out, _, _ = self._eval(0, Z)
+        return out + lam * Z
+
+    def hessp(self, S, lam):
+        """src/imc.py:91-96, including its quirk: the SCALAR lam is added to every
+        entry (pinned by the reference's tests/test_imc.py:70-80)."""
+        out, _, _ = self._eval(1, S)
+        return out + lam
+
+    def init_z(self):
+        """src/imc.py:157-159: X^T diag(R) Y / R.size pushed through an SVD."""
+        neg = -self.ratings
+        out, _, _ = self._eval(0, np.zeros((self.p, self.q)), ratings=neg)
+        z0 = out / self.n_samples
+        u, s, v = np.linalg.svd(z0, False)
+        return u.dot(np.diag(s)).dot(v)
+
+    def predict_samples(self, Z):
+        """x_e^T Z y_e for every sample, in the caller's sample order."""
+        _, _, pred = self._eval(1, Z, want_out=False, want_pred=True)
+        return pred
+
+    def sse(self, Z):
+        _, sse, _ = self._eval(0, Z, want_out=False, want_sse=True)
+        return sse
+
+
+def problem_from_samples(users, items, ratings, dtype=np.float64):
+    """Per-sample feature matrices (the reference's form) as an index-form problem
+    in which every sample is its own 'user' and its own 'item'."""
+    users = np.atleast_2d(np.asarray(users))
+    items = np.atleast_2d(np.asarray(items))
+    n_s = users.shape[0]
+    idx = np.arange(n_s)
+    return ImcProblem(users, items, idx, idx, ratings, dtype=dtype)
+
+
+_problem_cache = {}
+
+
+def _cached_problem(users, items, ratings):
+    """The scipy callbacks receive the same (users, items, ratings) objects on
+    every call; keep their device copy instead of re-uploading per evaluation."""
+    key = (id(users), id(items), id(ratings), np.shape(users), np.shape(items))
+    hit = _problem_cache.get(key)
+    if hit is not None and hit[0] is users and hit[1] is items and hit[2] is ratings:
+        return hit[3]
+    if isinstance(users, ImcProblem):
+        prob = users
+    else:
+        prob = problem_from_samples(users, items, ratings)
+    _problem_cache.clear()
+    _problem_cache[key] = (users, items, ratings, prob)
+    return prob
+
+
+def _cost(arr, *args):
+    """Regularised sum of squared errors (src/imc.py:30-48)."""
+    users, items, ratings, lam, shape = args
+    return _cached_problem(users, items, ratings).cost(np.asarray(arr).reshape(shape), lam)
+
+
+def _cost_prime(arr, *args):
+    """Gradient of ``_cost`` w.r.t. Z, flattened (src/imc.py:51-71)."""
+    users, items, ratings, lam, shape = args
+    prob = _cached_problem(users, items, ratings)
+    return prob.grad(np.asarray(arr).reshape(shape), lam).ravel()
+
+
+def _cost_hess(_, s_vec, *args):
+    """Hessian-vector product, flattened (src/imc.py:74-96)."""
+    users, items, ratings, lam, shape = args
+    prob = _cached_problem(users, items, ratings)
+    return prob.hessp(np.asarray(s_vec).reshape(shape), lam).ravel()
+
+
+def _fit_problem(prob, Z, method, alpha, verbose):
+    if Z is None:
+        Z = prob.init_z()
+    Z = np.asarray(Z, dtype=np.float64)
+    shape = Z.shape
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=RuntimeWarning)
+        res = so.minimize(
+            lambda a: prob.cost(a.reshape(shape), alpha), Z.flatten(), method=method,
+            jac=lambda a: prob.grad(a.reshape(shape), alpha).ravel(),
+            hessp=lambda a, s: prob.hessp(s.reshape(shape), alpha).ravel(),
+            options={'disp': verbose})
+    return res['x'].reshape(shape), res.success, res.message
+
+
+def _fit_imc(X, Y, R, Z=None, method='Newton-CG', n_components=None,
+             alpha=0.1, verbose=0):
+    """Minimise the IMC objective over Z for per-sample features X, Y and ratings
+    R; returns ``(Z, success, message)`` (src/imc.py:99-170)."""
+    _, n_features = np.atleast_2d(X).shape
+    if n_components is None:
+        n_components = n_features
+    if not isinstance(n_components, INTEGER_TYPES) or n_components <= 0:
+        raise ValueError("Number of components must be a positive integer;"
+                         " got (n_components=%r)." % n_components)
+    prob = problem_from_samples(X, Y, R)
+    return _fit_problem(prob, Z, method, alpha, verbose)
+
+
+class IMC(BaseEstimator):
+    """Inductive matrix completion estimator (src/imc.py:173-356)."""
+
+    def __init__(self, n_components=None, method='Newton-CG', alpha=0.1,
+                 verbose=0):
+        self.n_components = n_components
+        self.method = method
+        self.alpha = alpha
+        self.verbose = verbose
+
+    @staticmethod
+    def _problem(X, y):
+        x, y_ = _check_x(X)
+        if issparse(y):
+            y = y.tocsr()
+            rows, cols = y.nonzero()
+            return ImcProblem(x, y_, rows, cols, np.asarray(y[rows, cols]).ravel())
+        return problem_from_samples(x, y_, y)
+
+    def fit_transform(self, X, y, Z=None):
+        """Learn Z for the given data and return it (src/imc.py:220-254)."""
+        x, _ = _check_x(X)
+        n_features = np.atleast_2d(x).shape[1]
+        if self.n_components and self.n_components < n_features:
+            self.n_components_ = self.n_components
+        else:
+            self.n_components_ = n_features
+        if not isinstance(self.n_components_, INTEGER_TYPES) or self.n_components_ <= 0:
+            raise ValueError("Number of components must be a positive integer;"
+                             " got (n_components=%r)." % self.n_components_)
+        prob = self._problem(X, y)
+        Z, success, msg = _fit_problem(prob, Z, self.method, self.alpha, self.verbose)
+        if not success:
+            warnings.warn(msg, ConvergenceWarning, stacklevel=1)
+        self.Z = Z
+        sse = prob.sse(Z)
+        self.reconstruction_err_ = float(np.sqrt(sse / prob.n_samples))
+        return Z
+
+    def fit(self, X, y, Z=None):
+        """src/imc.py:256-276."""
+        _ = self.fit_transform(X, y, Z=Z)
+        return self
+
+    def _predict(self, X):
+        """X Z Y^T for attribute matrices X (n x p), Y (m x q): the full n x m
+        matrix; 1-D rows give a scalar (src/imc.py:278-295)."""
+        x, y_ = _check_x(X)
+        x_arr, y_arr = np.asarray(x), np.asarray(y_)
+        x2, y2 = np.atleast_2d(x_arr), np.atleast_2d(y_arr)
+        n, m = x2.shape[0], y2.shape[0]
+        rows = np.repeat(np.arange(n), m)
+        cols = np.tile(np.arange(m), n)
+        prob = ImcProblem(x2, y2, rows, cols, np.zeros(n * m))
+        pred = prob.predict_samples(self.Z).reshape(n, m)
+        if x_arr.ndim == 1 and y_arr.ndim == 1:
+            return pred[0, 0]
+        if x_arr.ndim == 1:
+            return pred[0]
+        if y_arr.ndim == 1:
+            return pred[:, 0]
+        return pred
+
+    def predict_one(self, X):
+        """src/imc.py:297-313."""
+        check_is_fitted(self, 'n_components_')
+        return self._predict(X)
+
+    def predict_all(self, X):
+        """src/imc.py:315-331."""
+        check_is_fitted(self, 'n_components_')
+        return self._predict(X)
+
+    def score(self, X, y):
+        """POSITIVE root mean squared error of the per-sample predictions
+        (src/imc.py:333-356; note the sign differs from ALS and DirtyIMC)."""
+        check_is_fitted(self, 'n_components_')
+        prob = self._problem(X, y)
+        preds = prob.predict_samples(self.Z)
+        truth = np.empty(prob.n_samples)
+        truth[prob.order] = prob.ratings.to(prob._torch.float64).cpu().numpy()
+        return root_mean_squared_error(truth, preds)

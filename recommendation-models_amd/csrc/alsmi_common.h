@@ -73,11 +73,21 @@ __device__ __forceinline__ int read_lane(int v, int lane) {
     return __builtin_amdgcn_readlane(v, lane);
 }
 
-// NV consecutive elements per lane, NV in {1, 2, 4, 8}; p is NV*sizeof(T) aligned.
+// NV consecutive elements per lane, NV in {1, 2, 4, 8, 16}; p is NV*sizeof(T) aligned.
 template <typename T, int NV>
 __device__ __forceinline__ void load_vec(T (&v)[NV], const T *p) {
+    static_assert(NV == 1 || NV == 2 || NV == 4 || NV == 8 || NV == 16, "unsupported width");
     if constexpr (NV == 1) {
         v[0] = p[0];
+    } else if constexpr (NV == 16) {
+        typedef T half_t __attribute__((ext_vector_type(8)));
+        const half_t lo = *reinterpret_cast<const half_t *>(p);
+        const half_t hi = *reinterpret_cast<const half_t *>(p + 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = lo[e];
+            v[8 + e] = hi[e];
+        }
     } else {
         typedef T vec_t __attribute__((ext_vector_type(NV)));
         const vec_t x = *reinterpret_cast<const vec_t *>(p);

@@ -1,2 +1,310 @@
-// IMC cost / gradient / Hessian-vector kernels (placeholder translation unit; filled in below).
+// IMC objective pieces for gfx950: masked residual as an SDDMM over the stored entries, the
+// side-feature products as an SpMM fused into the same pass plus two dense MFMA GEMMs.
+//
+// Replaces the dense per-sample arithmetic of the reference's _cost, _cost_prime and
+// _cost_hess (src/imc.py:43-48, :65-71, :91-96).  The reference materialises one feature row
+// per SAMPLE (n_s x p and n_s x q); here the attribute matrices stay per user / per item and
+// the samples are (user, item) index pairs grouped by user:
+//     A   = X M                         dense GEMM   [n_users x q]
+//     d_e = <A[u_e], Y[i_e]>            SDDMM over the stored entries
+//     W_u = sum_{e in u} w_e Y[i_e]     SpMM, same pass (w = d - r for the gradient, d for Hv)
+//     out = X^T W                       dense GEMM, reduction over users split in slices
+// The regulariser terms of the reference (lam*||Z||^2 per sample, lam*Z, the scalar lam of the
+// Hessian-vector product) are O(p q) and are added by the caller.
+//
+// Layout: Y and the two workspace tables A, W are row-major with the row stride padded to
+// ld = the next of 16/32/64/128/256 that is >= q (pad columns zero) so that 16 lanes read one
+// contiguous row, four rows per wave instruction, exactly like the ALS factor gather.  X [n_users x p] and M [p x q] are
+// plain row-major.
 #include "alsmi_common.h"
+
+namespace alsmi {
+
+constexpr int IMC_MAX_Q = 256;
+constexpr int IMC_SSE_BLOCKS = 2048;
+constexpr int IMC_KSPLIT = 128;
+
+// ---- C[M x N] (+)= op(A) B with one 16x16 tile per wave on v_mfma_*_16x16x4 --------------
+// TRANS_A = false: A is [M x K] row-major (lda).  TRANS_A = true: A is [K x M] row-major.
+// B is [K x NB] row-major (ldb) with NB <= N real columns; output columns NB..N-1 are written
+// as zero (that is how a table with a padded row stride gets its zero pad columns).
+// Out-of-range operand elements read as zero, so any M, N, K work.  The K range is cut into
+// gridDim.z slices; slice z writes its tile to C + z * slice_stride (partial results, summed
+// in slice order by reduce_partials_kernel).
+template <typename T, bool TRANS_A>
+__global__ __launch_bounds__(256) void gemm16_kernel(int M, int N, int NB, int64_t K,
+                                                     const T *__restrict__ A, int64_t lda,
+                                                     const T *__restrict__ B, int64_t ldb,
+                                                     T *__restrict__ C, int64_t ldc,
+                                                     int64_t slice_stride) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int tiles_n = (N + 15) >> 4;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_tiles = (int64_t)((M + 15) >> 4) * tiles_n;
+    if (tile >= n_tiles) return;
+    const int i0 = (int)(tile / tiles_n) * 16, j0 = (int)(tile % tiles_n) * 16;
+    const int64_t kslice = (K + gridDim.z - 1) / gridDim.z;
+    const int64_t kb = (int64_t)blockIdx.z * kslice;
+    const int64_t ke = kb + kslice < K ? kb + kslice : K;
+    typename Mfma<T>::acc_t acc = {0, 0, 0, 0};
+    const bool row_ok = i0 + q < M, col_ok = j0 + q < N, bcol_ok = j0 + q < NB;
+    for (int64_t k0 = kb; k0 < ke; k0 += 4) {
+        const int64_t k = k0 + g;
+        T a = T(0), b = T(0);
+        if (k < ke) {
+            if (row_ok) a = TRANS_A ? A[k * lda + i0 + q] : A[(int64_t)(i0 + q) * lda + k];
+            if (bcol_ok) b = B[k * ldb + j0 + q];
+        }
+        acc = Mfma<T>::mma(a, b, acc);
+    }
+    T *Cz = C + (int64_t)blockIdx.z * slice_stride;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + Mfma<T>::crow(g, r);
+        if (i < M && col_ok) Cz[(int64_t)i * ldc + j0 + q] = acc[r];
+    }
+}
+
+// out[i] = sum_z partials[z * count + i], fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const T *__restrict__ partials,
+                                                              int nz, int64_t count,
+                                                              T *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    T s = T(0);
+    for (int z = 0; z < nz; ++z) s += partials[(int64_t)z * count + i];
+    out[i] = s;
+}
+
+// ---- fused SDDMM + SpMM over the entries of each user -----------------------------------------
+// One wave per user row at a time.  mode 0: w = d - r and the squared error is accumulated;
+// mode 1: w = d.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void imc_rows_kernel(int mode, int64_t n_users,
+                                                       const int64_t *__restrict__ indptr,
+                                                       const int32_t *__restrict__ items,
+                                                       const T *__restrict__ ratings,
+                                                       const T *__restrict__ Atab,
+                                                       const T *__restrict__ Y,
+                                                       T *__restrict__ W,
+                                                       T *__restrict__ pred_out,
+                                                       double *__restrict__ partials) {
+    constexpr int LD = NV * 16;
+    __shared__ double wsum[4];
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int wl = threadIdx.x >> 6;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    double sse = 0.0;
+    for (int64_t u = (int64_t)blockIdx.x * 4 + wl; u < n_users; u += nw) {
+        const int64_t beg = indptr[u], end = indptr[u + 1];
+        T a[NV], wacc[NV];
+        load_vec<T, NV>(a, Atab + u * LD + q * NV);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) wacc[e] = T(0);
+        for (int64_t base = beg; base < end; base += WAVE) {
+            const int64_t left = end - base;
+            const int cnt = left < WAVE ? (int)left : WAVE;
+            int it = 0;
+            T r = T(0);
+            if (lane < cnt) {
+                it = items[base + lane];
+                if (mode == 0) r = ratings[base + lane];
+            }
+            const int nsteps = (cnt + 3) >> 2;
+            for (int s = 0; s < nsteps; ++s) {
+                const int sl = 4 * s + g;
+                const int id = __shfl(it, sl);
+                const T rr = __shfl(r, sl);
+                T y[NV];
+                load_vec<T, NV>(y, Y + (int64_t)id * LD + q * NV);
+                T d = T(0);
+#pragma unroll
+                for (int e = 0; e < NV; ++e) d += a[e] * y[e];
+                d += __shfl_xor(d, 1);
+                d += __shfl_xor(d, 2);
+                d += __shfl_xor(d, 4);
+                d += __shfl_xor(d, 8);
+                T w = T(0);
+                if (sl < cnt) {
+                    w = mode == 0 ? d - rr : d;
+                    if (q == 0) {
+                        if (pred_out) pred_out[base + sl] = d;
+                        if (mode == 0) {
+                            const double err = (double)rr - (double)d;
+                            sse += err * err;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NV; ++e) wacc[e] += w * y[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            wacc[e] += __shfl_xor(wacc[e], 16);
+            wacc[e] += __shfl_xor(wacc[e], 32);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) W[u * LD + q * NV + e] = wacc[e];
+        }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) wsum[wl] = sse;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(256) void imc_sum_sse_kernel(const double *__restrict__ partials,
+                                                          int n, double *__restrict__ out) {
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// Row stride of Y and of the A / W workspace tables: the next of 16/32/64/128/256 >= q, so
+// that each of the 16 lanes of a row group owns a power-of-two number of elements.
+static int imc_ld(int q) {
+    int ld = 16;
+    while (ld < q) ld *= 2;
+    return ld;
+}
+
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct ImcWorkspace {
+    size_t a_off, w_off, part_off, sse_off, total;
+};
+
+static ImcWorkspace imc_layout(size_t esz, int64_t n_users, int p, int q) {
+    ImcWorkspace ws;
+    const size_t table = align256((size_t)n_users * imc_ld(q) * esz);
+    ws.a_off = 0;
+    ws.w_off = table;
+    ws.part_off = 2 * table;
+    ws.sse_off = ws.part_off + align256((size_t)IMC_KSPLIT * p * q * esz);
+    ws.total = ws.sse_off + align256(IMC_SSE_BLOCKS * sizeof(double));
+    return ws;
+}
+
+template <typename T, int NV>
+static void launch_rows(int grid, int mode, int64_t n_users, const int64_t *indptr,
+                        const int32_t *items, const void *ratings, const T *Atab, const void *Y,
+                        T *Wtab, void *pred_out, double *sse_part, hipStream_t st) {
+    hipLaunchKernelGGL((imc_rows_kernel<T, NV>), dim3(grid), dim3(256), 0, st, mode, n_users,
+                       indptr, items, static_cast<const T *>(ratings), Atab,
+                       static_cast<const T *>(Y), Wtab, static_cast<T *>(pred_out), sse_part);
+}
+
+template <typename T>
+static int run_imc_eval(int mode, int64_t n_users, int p, int q, const int64_t *indptr,
+                        const int32_t *items, const void *ratings, const void *X, const void *Y,
+                        const void *Mmat, void *out, void *pred_out, double *sse_out,
+                        void *workspace, hipStream_t st) {
+    const int ld = imc_ld(q);
+    const ImcWorkspace ws = imc_layout(sizeof(T), n_users, p, q);
+    char *base = static_cast<char *>(workspace);
+    T *Atab = reinterpret_cast<T *>(base + ws.a_off);
+    T *Wtab = reinterpret_cast<T *>(base + ws.w_off);
+    T *part = reinterpret_cast<T *>(base + ws.part_off);
+    double *sse_part = reinterpret_cast<double *>(base + ws.sse_off);
+
+    // A = X M with the padded row stride; M has q real columns, the pad columns come out zero
+    const int64_t tiles_a = ((n_users + 15) / 16) * (ld / 16);
+    hipLaunchKernelGGL((gemm16_kernel<T, false>), dim3((unsigned)((tiles_a + 3) / 4), 1, 1),
+                       dim3(256), 0, st, (int)n_users, ld, q, (int64_t)p,
+                       static_cast<const T *>(X), (int64_t)p, static_cast<const T *>(Mmat),
+                       (int64_t)q, Atab, (int64_t)ld, (int64_t)0);
+    ALSMI_HIP_CHECK(hipGetLastError());
+
+    // d_e, squared error, W = (weights) x Y in one pass over the stored entries
+    int64_t want = (n_users + 3) / 4;
+    const int grid = (int)(want < 1 ? 1 : (want < IMC_SSE_BLOCKS ? want : IMC_SSE_BLOCKS));
+    switch (ld / 16) {
+        case 1: launch_rows<T, 1>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
+        case 2: launch_rows<T, 2>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
+        case 4: launch_rows<T, 4>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
+        case 8: launch_rows<T, 8>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
+        case 16: launch_rows<T, 16>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
+        default:
+            set_error("alsmi_imc_eval: unsupported padded width %d", ld);
+            return ALSMI_EINVAL;
+    }
+    ALSMI_HIP_CHECK(hipGetLastError());
+    if (sse_out) {
+        hipLaunchKernelGGL(imc_sum_sse_kernel, dim3(1), dim3(256), 0, st, sse_part, grid, sse_out);
+        ALSMI_HIP_CHECK(hipGetLastError());
+    }
+
+    // out = X^T W: the reduction over users is cut into slices whose partial p x q products
+    // are added in slice order (reproducible for a given n_users)
+    if (out) {
+        int ksplit = (int)((n_users + 255) / 256);
+        if (ksplit > IMC_KSPLIT) ksplit = IMC_KSPLIT;
+        if (ksplit < 1) ksplit = 1;
+        const int64_t tiles_o = (int64_t)((p + 15) / 16) * ((q + 15) / 16);
+        const int64_t count = (int64_t)p * q;
+        hipLaunchKernelGGL((gemm16_kernel<T, true>),
+                           dim3((unsigned)((tiles_o + 3) / 4), 1, (unsigned)ksplit), dim3(256), 0,
+                           st, p, q, q, n_users, static_cast<const T *>(X), (int64_t)p, Wtab,
+                           (int64_t)ld, part, (int64_t)q, count);
+        ALSMI_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((count + 255) / 256)),
+                           dim3(256), 0, st, part, ksplit, count, static_cast<T *>(out));
+        ALSMI_HIP_CHECK(hipGetLastError());
+    }
+    return ALSMI_OK;
+}
+
+}  // namespace alsmi
+
+extern "C" {
+
+int alsmi_imc_padded_width(int q) {
+    if (q < 1 || q > alsmi::IMC_MAX_Q) return 0;
+    return alsmi::imc_ld(q);
+}
+
+size_t alsmi_imc_workspace_bytes(int dtype, int64_t n_users, int p, int q) {
+    if ((dtype != ALSMI_F32 && dtype != ALSMI_F64) || n_users < 0 || p < 1 || q < 1 ||
+        q > alsmi::IMC_MAX_Q)
+        return 0;
+    return alsmi::imc_layout(dtype == ALSMI_F32 ? 4 : 8, n_users, p, q).total;
+}
+
+int alsmi_imc_eval(int dtype, int mode, int64_t n_users, int p, int q, const int64_t *indptr,
+                   const int32_t *items, const void *ratings, const void *X, const void *Y,
+                   const void *M, void *out, void *pred_out, double *sse_out, void *workspace,
+                   void *stream) {
+    using namespace alsmi;
+    ALSMI_REQUIRE(dtype == ALSMI_F32 || dtype == ALSMI_F64, "alsmi_imc_eval: bad dtype %d", dtype);
+    ALSMI_REQUIRE(mode == 0 || mode == 1, "alsmi_imc_eval: mode must be 0 or 1, got %d", mode);
+    ALSMI_REQUIRE(p >= 1 && q >= 1 && q <= IMC_MAX_Q,
+                  "alsmi_imc_eval: need p >= 1 and 1 <= q <= %d (got p=%d q=%d)", IMC_MAX_Q, p, q);
+    ALSMI_REQUIRE(n_users >= 0 && n_users < INT32_MAX, "alsmi_imc_eval: bad user count");
+    ALSMI_REQUIRE(mode == 0 || !sse_out, "alsmi_imc_eval: sse_out only exists in mode 0");
+    if (n_users == 0) {
+        ALSMI_REQUIRE(!out && !sse_out && !pred_out, "alsmi_imc_eval: no users, nothing to write");
+        return ALSMI_OK;
+    }
+    ALSMI_REQUIRE(indptr && X && Y && M && workspace, "alsmi_imc_eval: null pointer");
+    ALSMI_REQUIRE(mode == 1 || ratings, "alsmi_imc_eval: mode 0 needs ratings");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALSMI_F32)
+        return run_imc_eval<float>(mode, n_users, p, q, indptr, items, ratings, X, Y, M, out,
+                                   pred_out, sse_out, workspace, st);
+    return run_imc_eval<double>(mode, n_users, p, q, indptr, items, ratings, X, Y, M, out,
+                                pred_out, sse_out, workspace, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+"""CPU stand-in for the device backend of alsmi.engine.AlsEngine, built on the
+oracle.  TEST INFRASTRUCTURE: it lets the sharding / all-gather / all-reduce logic
+of the engine run under the gloo backend on machines without a GPU.  The product
+never constructs it."""
+import numpy as np
+import torch
+
+from oracle import c_oracle as co
+
+
+class OracleSide(object):
+    def __init__(self, indptr, indices, vals, n_rows, n_cols, dtype):
+        as_np = lambda a: a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+        self.indptr_host = np.ascontiguousarray(as_np(indptr), dtype=np.int64)
+        self.indices_np = np.ascontiguousarray(as_np(indices), dtype=np.int32)
+        self.vals_np = np.ascontiguousarray(as_np(vals), dtype=np.float64)
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.nnz = int(self.indptr_host[-1])
+        self.indices = torch.from_numpy(self.indices_np)
+        self.vals = torch.from_numpy(self.vals_np)
+        self.dtype = np.dtype(np.float64)
+
+    def expand_rows(self):
+        rows = np.repeat(np.arange(self.n_rows, dtype=np.int32), np.diff(self.indptr_host))
+        return torch.from_numpy(rows)
+
+
+class OraclePlan(object):
+    def __init__(self, side, rank):
+        self.side, self.rank = side, rank
+
+    def half_sweep(self, src, dst, alpha):
+        s = self.side
+        if s.n_rows == 0:
+            return
+        out = co.half_sweep(s.indptr_host, s.indices_np, s.vals_np,
+                            src[:, :self.rank].numpy(), alpha, threads=1)
+        dst[:s.n_rows, :self.rank] = torch.from_numpy(out)
+
+
+class OracleBackend(object):
+    def make_side(self, indptr, indices, vals, n_rows, n_cols, dtype):
+        return OracleSide(indptr, indices, vals, n_rows, n_cols, dtype)
+
+    def make_plan(self, side, rank, chunk):
+        return OraclePlan(side, rank)
+
+    def zeros(self, rows, cols, dtype):
+        return torch.zeros((rows, cols), dtype=torch.float64)
+
+    def padded_rank(self, rank):
+        return 16 if rank <= 16 else 32 if rank <= 32 else 64 if rank <= 64 else 128
+
+    def sddmm(self, rank, users, items, row_table, col_table, vals, want_pred):
+        u = row_table[users.long(), :rank]
+        v = col_table[items.long(), :rank]
+        pred = (u * v).sum(-1)
+        sse = ((vals - pred) ** 2).sum().reshape(1) if vals is not None else None
+        return (pred if want_pred else None), sse

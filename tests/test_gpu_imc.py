@@ -1,0 +1,185 @@
+"""HIP IMC / DirtyIMC path against the oracle and the reference's golden vectors."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    from alsmi import device as dev
+    return dev.require_gpu()
+
+
+def unit_data(g):
+    X, Y = g['X'], g['Y']
+    R = sps.csr_matrix(g['R'])
+    rows, cols = g['rows'], g['cols']
+    return X, Y, R, X[rows], Y[cols], np.asarray(R[rows, cols]).ravel().astype(np.float64)
+
+
+def test_callbacks_known_answers(gpu, golden):
+    """reference tests/test_imc.py:53-80 through the scipy-callback signature."""
+    from alsmi.imc import _cost, _cost_hess, _cost_prime
+    g = golden('imc_unit')
+    _, _, _, x_h, y_h, b_h = unit_data(g)
+    args = (x_h, y_h, b_h, 0.01, (15, 20))
+    assert _cost(np.zeros(300), *args) == 130545000.0
+    np.testing.assert_allclose(_cost_prime(np.zeros(300), *args)[:10],
+                               [-300, 0, 0, 0, -6000, 0, -300, 0, -6000, 0])
+    np.testing.assert_allclose(_cost_hess(np.zeros(300), np.arange(300), *args)[:10],
+                               [1.54801e3, 0.01, 0.01, 0.01, 1.56001e3, 0.01, 1.54801e3, 0.01,
+                                1.56001e3, 0.01])
+    np.testing.assert_allclose(_cost_prime(np.zeros(300), *args), g['grad0'], rtol=1e-12,
+                               atol=1e-9)
+    np.testing.assert_allclose(_cost_hess(np.zeros(300), np.arange(300), *args), g['hess0'],
+                               rtol=1e-12)
+
+
+@pytest.mark.parametrize('form', ['samples', 'indexed'])
+def test_evaluations_match_reference_vectors(gpu, golden, form):
+    from alsmi.imc import ImcProblem, problem_from_samples
+    from oracle import imc_oracle as io
+    g = golden('imc_random')
+    X, Y, users, items, vals = g['X'], g['Y'], g['users'], g['items'], g['vals']
+    Z, S, lam = g['Z'], g['S'], float(g['lam'])
+    if form == 'samples':
+        prob = problem_from_samples(X[users], Y[items], vals)
+    else:
+        # shuffled sample order: grouping by user must not change anything
+        perm = np.random.default_rng(0).permutation(vals.size)
+        prob = ImcProblem(X, Y, users[perm], items[perm], vals[perm])
+    np.testing.assert_allclose(prob.cost(Z, lam), g['cost'], rtol=1e-12)
+    np.testing.assert_allclose(prob.grad(Z, lam).ravel(), g['grad'], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(prob.hessp(S, lam).ravel(), g['hessp'], rtol=1e-10, atol=1e-10)
+    z0 = prob.init_z()
+    np.testing.assert_allclose(z0, g['Z0'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(z0, io.init_z(X, Y, users, items, vals), rtol=1e-9, atol=1e-12)
+    want = io.preds_indexed(Z, X, Y, users, items)
+    got = prob.predict_samples(Z)
+    if form == 'indexed':
+        want = want[perm]
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('p,q', [(3, 1), (17, 16), (5, 33), (130, 100), (40, 256)])
+def test_evaluations_match_oracle_shapes(gpu, p, q):
+    """attribute widths around every padding boundary, empty users, one long user."""
+    from alsmi.imc import ImcProblem
+    from oracle import imc_oracle as io
+    rng = np.random.default_rng(p * 1000 + q)
+    n, m, nnz = 70, 50, 900
+    flat = rng.choice(n * m, size=nnz, replace=False)
+    users, items = flat // m, flat % m
+    keep = ~np.isin(users, (0, 13, 69))
+    users, items = users[keep], items[keep]
+    users = np.concatenate([users, np.full(m, 13)])
+    items = np.concatenate([items, np.arange(m)])
+    vals = rng.standard_normal(users.size)
+    X = rng.standard_normal((n, p)) / np.sqrt(p)
+    Y = rng.standard_normal((m, q)) / np.sqrt(q)
+    Z, S = rng.standard_normal((p, q)), rng.standard_normal((p, q))
+    prob = ImcProblem(X, Y, users, items, vals)
+    np.testing.assert_allclose(prob.cost(Z, 0.3), io.cost_indexed(Z, X, Y, users, items, vals, 0.3),
+                               rtol=1e-12)
+    np.testing.assert_allclose(prob.grad(Z, 0.3), io.grad_indexed(Z, X, Y, users, items, vals, 0.3),
+                               rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(prob.hessp(S, 0.3), io.hessp_indexed(S, X, Y, users, items, 0.3),
+                               rtol=1e-10, atol=1e-10)
+
+
+def test_imc_estimator_known_answers(gpu, golden):
+    """reference tests/test_imc.py:121-210 in both input forms."""
+    from alsmi import IMC
+    g = golden('imc_unit')
+    X, Y, R, x_h, y_h, b_h = unit_data(g)
+    for args in (((x_h, y_h), b_h), ((X, Y), R)):
+        imc = IMC(alpha=0.01)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Z = imc.fit_transform(*args)
+        np.testing.assert_allclose(Z, g['imc0_Z'], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(Z[0, [0, 4, 6, 8]],
+                                   [-1.06455138e2, 5.26175380e2, -1.06455138e2, 5.26175380e2],
+                                   rtol=1e-7)
+        np.testing.assert_allclose(imc.reconstruction_err_, 5.748504798089005, rtol=1e-8)
+        np.testing.assert_allclose(imc.score(*args), 5.748504798089005, rtol=1e-8)
+        np.testing.assert_allclose(imc.predict_one((X[0], Y[0])), 301.06449075427315, rtol=1e-8)
+        np.testing.assert_allclose(imc._predict((X[[0]], Y[[0]])), 301.06449075427315, rtol=1e-8)
+        np.testing.assert_allclose(imc.predict_all((X, Y)),
+                                   [[301.06449075, 5994.73915285],
+                                    [8994.67063528, 11991.34151006]], rtol=1e-8)
+    imck = IMC(n_components=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Zk = imck.fit_transform((x_h, y_h), b_h)
+    assert imck.n_components_ == int(g['imck_n_components_'])
+    np.testing.assert_allclose(Zk[0, :10], [-1.0457636e2, -1.35697449e-3, -1.35697449e-3,
+                                            -1.35697449e-3, 5.217910e2, -1.35697449e-3,
+                                            -1.0457636e2, -1.35697449e-3, 5.217910e2,
+                                            -1.35697449e-3], rtol=1e-6)
+
+
+def test_fit_imc_and_errors(gpu, golden):
+    from sklearn.exceptions import NotFittedError
+    from alsmi import IMC
+    from alsmi.imc import _fit_imc
+    g = golden('imc_unit')
+    X, Y, _, x_h, y_h, b_h = unit_data(g)
+    with pytest.raises(ValueError) as ctx:
+        _fit_imc(x_h, y_h, b_h, n_components=0)
+    assert str(ctx.value) == ('Number of components must be a positive integer; '
+                              'got (n_components=0).')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Z, succ, _ = _fit_imc(x_h, y_h, b_h)
+    np.testing.assert_allclose(Z, g['fit_default_Z'], rtol=1e-6, atol=1e-8)
+    assert bool(succ) == bool(g['fit_default_success'])
+    with pytest.raises(NotFittedError):
+        IMC(alpha=0.01).predict_one((X[0], Y[0]))
+
+
+def test_imc_random_fit(gpu, golden):
+    from alsmi import IMC
+    g = golden('imc_random')
+    X, Y, users, items, vals = g['X'], g['Y'], g['users'], g['items'], g['vals']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        imc = IMC(alpha=float(g['lam'])).fit((X[users], Y[items]), vals)
+    np.testing.assert_allclose(imc.Z, g['fit_Z'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(imc.reconstruction_err_, g['fit_err'], rtol=1e-8)
+
+
+def test_dimc_matches_reference(gpu, golden):
+    from alsmi import DirtyIMC
+    g = golden('dimc')
+    X, Y = g['X'], g['Y']
+    R = sps.csr_matrix(g['R'])
+    rows, cols = g['rows'], g['cols']
+    x_h, y_h = X[rows], Y[cols]
+    for tag, y, kw in (('sparse', R, {}), ('dense', np.asarray(R[rows, cols]).ravel(),
+                                           {'shape': R.shape})):
+        d = DirtyIMC(rank=2, tol=1e-6, random_state=42, imc_alpha=0.01)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Z, u, i = d.fit_transform((x_h, y_h, rows, cols), y, **kw)
+        np.testing.assert_allclose(d.reconstruction_err_, -0.14143343218755264, rtol=1e-5)
+        np.testing.assert_allclose(d.predict((x_h, y_h, rows, cols)), g['predict_' + tag],
+                                   rtol=1e-7)
+    with pytest.raises(ValueError) as ctx:
+        d.fit((x_h, y_h, rows, cols), np.asarray(R[rows, cols]).ravel())
+    assert str(ctx.value) == 'When y is a scalar or 1-D array shape must be' + 'provided.'
+    users, items = g['rnd_users'], g['rnd_items']
+    n, m = (int(v) for v in g['rnd_shape'])
+    d = DirtyIMC(rank=3, tol=1e-3, random_state=5, imc_alpha=0.1, als_alpha=0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Z, u, i = d.fit_transform((g['rnd_X'][users], g['rnd_Y'][items], users, items),
+                                  g['rnd_vals'], shape=(n, m))
+    np.testing.assert_allclose(Z, g['rnd_Z'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(d.reconstruction_err_, g['rnd_err'], rtol=1e-6)
+    np.testing.assert_allclose(d.predict((g['rnd_X'][users], g['rnd_Y'][items], users, items)),
+                               g['rnd_predict'], rtol=1e-5, atol=1e-6)
