@@ -77,47 +77,63 @@ __device__ __forceinline__ void gram_step(Gram<T, NV> &G, const T (&v)[NV], T rv
             G.acc[tri_index(e, f, NV)] = Mfma<T>::mma(v[e], v[f], G.acc[tri_index(e, f, NV)]);
 }
 
-// Accumulate entries [beg, end) of one row.
+// U consecutive k=4 steps starting at step s: issue all their gathers first, then the MFMAs.
+template <typename T, int NV, int U>
+__device__ __forceinline__ void gram_steps(Gram<T, NV> &G, const T *__restrict__ srcq, int idx,
+                                           T rv, int s, int g) {
+    constexpr int KP = NV * 16;
+    T v[U][NV];
+    T r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int sl = 4 * (s + u) + g;
+        const int id = __shfl(idx, sl);
+        r[u] = __shfl(rv, sl);
+        load_vec<T, NV>(v[u], srcq + (int64_t)id * KP);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) gram_step<T, NV>(G, v[u], r[u]);
+}
+
+// Accumulate entries [beg, end) of one row.  The index / rating block of the next 64 entries
+// is requested before the current block is processed.
 template <typename T, int NV>
 __device__ __forceinline__ void gram_range(Gram<T, NV> &G, const int32_t *__restrict__ indices,
                                            const T *__restrict__ vals,
                                            const T *__restrict__ src, int64_t beg, int64_t end,
                                            int lane) {
     constexpr int KP = NV * 16;
+    // registers: 8 steps in flight cost 8*NV operand registers per lane
+    constexpr int DEEP = (NV * (int)sizeof(T) <= 16) ? 8 : 4;
     const int g = lane >> 4, q = lane & 15;
     const T *srcq = src + q * NV;
+    int idx_n = 0;
+    T rv_n = T(0);
+    if (beg + lane < end) {
+        idx_n = indices[beg + lane];
+        rv_n = vals[beg + lane];
+    }
     for (int64_t base = beg; base < end; base += WAVE) {
         const int64_t left = end - base;
         const int cnt = left < WAVE ? (int)left : WAVE;
-        int idx = 0;
-        T rv = T(0);
-        if (lane < cnt) {
-            idx = indices[base + lane];
-            rv = vals[base + lane];
+        const int idx = idx_n;
+        const T rv = rv_n;
+        idx_n = 0;
+        rv_n = T(0);
+        if (base + WAVE + lane < end) {
+            idx_n = indices[base + WAVE + lane];
+            rv_n = vals[base + WAVE + lane];
         }
         const int nfull = cnt >> 2;
         int s = 0;
-        for (; s + 4 <= nfull; s += 4) {
-            T v[4][NV];
-            T r4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int sl = 4 * (s + u) + g;
-                const int id = __shfl(idx, sl);
-                r4[u] = __shfl(rv, sl);
-                load_vec<T, NV>(v[u], srcq + (int64_t)id * KP);
+        for (; s + DEEP <= nfull; s += DEEP) gram_steps<T, NV, DEEP>(G, srcq, idx, rv, s, g);
+        if constexpr (DEEP > 4) {
+            if (s + 4 <= nfull) {
+                gram_steps<T, NV, 4>(G, srcq, idx, rv, s, g);
+                s += 4;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) gram_step<T, NV>(G, v[u], r4[u]);
         }
-        for (; s < nfull; ++s) {
-            const int sl = 4 * s + g;
-            const int id = __shfl(idx, sl);
-            const T r1 = __shfl(rv, sl);
-            T v[NV];
-            load_vec<T, NV>(v, srcq + (int64_t)id * KP);
-            gram_step<T, NV>(G, v, r1);
-        }
+        for (; s < nfull; ++s) gram_steps<T, NV, 1>(G, srcq, idx, rv, s, g);
         if (cnt & 3) {  // last, partial step: lanes past the end contribute zeros
             const int sl = 4 * nfull + g;
             const int id = __shfl(idx, sl);
@@ -145,6 +161,27 @@ __global__ __launch_bounds__(256) void gram_chunks_kernel(
     G.zero();
     gram_range<T, NV>(G, indices, vals, src, ch_beg[w], ch_end[w], lane);
     G.store(slabs + (size_t)w * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
+}
+
+// ---- kernel 1b: add the slabs of each long row into its first slab -----------------------
+// One thread per (row, accumulator element); the chunks are added in chunk order, so the sum
+// is reproducible.  Replaces a serial walk over up to dozens of slabs by the wave that solves
+// the row.
+template <typename T>
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const int32_t *__restrict__ slab_first,
+                                                        const int32_t *__restrict__ slab_count,
+                                                        int n_heavy, int slab_elems,
+                                                        T *__restrict__ slabs) {
+    const int per_row = (slab_elems + 255) / 256;
+    const int t = blockIdx.x / per_row;
+    if (t >= n_heavy) return;
+    const int i = (blockIdx.x % per_row) * 256 + threadIdx.x;
+    if (i >= slab_elems) return;
+    const int nch = slab_count[t];
+    T *first = slabs + (size_t)slab_first[t] * slab_elems;
+    T sum = first[i];
+    for (int c = 1; c < nch; ++c) sum += first[(size_t)c * slab_elems + i];
+    first[i] = sum;
 }
 
 // ---- LDS slab geometry ---------------------------------------------------------------------
@@ -202,6 +239,132 @@ __device__ __forceinline__ float pivot_rcp(float d) {
     return fmaf(r, fmaf(-d, r, 1.0f), r);
 }
 __device__ __forceinline__ double pivot_rcp(double d) { return 1.0 / d; }
+
+// ---- fast solve path (padded rank <= 64): registers only, LDS just for a small stage ----------
+// LDS per wave: a [KP x 16] transposition stage (row stride padded) and the right-hand side.
+template <typename T, int KP>
+struct Stage {
+    static constexpr int PAD = 16 / (int)sizeof(T);
+    static constexpr int LD = 16 + PAD;
+    static constexpr int ELEMS = KP * LD + KP;
+    static constexpr size_t BYTES = (size_t)ELEMS * sizeof(T);
+};
+
+// alpha*n on the diagonal of the real dimensions, 1 on the pad dimensions, applied to the
+// accumulators in place: the diagonal of tile (e,e) sits where the tile row equals the lane's
+// column.
+template <typename T, int NV>
+__device__ __forceinline__ void add_ridge(Gram<T, NV> &G, int lane, int rank, T ridge) {
+    const int g = lane >> 4, q = lane & 15;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool diag = Mfma<T>::crow(g, r) == q;
+            const T add = (q * NV + e < rank) ? ridge : T(1);
+            G.acc[tri_index(e, e, NV)][r] += diag ? add : T(0);
+        }
+}
+
+// Accumulator tiles -> one matrix row per lane, NV passes of 16 columns each through the
+// stage.  Pass f moves the columns {c*NV + f}: tiles (e,f) with e <= f are stored as they are,
+// tiles with e > f come from tile (f,e) by symmetry.  a[] ends up in natural column order.
+template <typename T, int NV>
+__device__ __forceinline__ void rows_to_regs(Gram<T, NV> &G, T *stage, T *bsm, int lane,
+                                             T (&a)[NV * 16], T &bb) {
+    constexpr int KP = NV * 16;
+    constexpr int LD = Stage<T, KP>::LD;
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    const int g = lane >> 4, q = lane & 15;
+    const int row = lane < KP ? lane : KP - 1;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        G.b[e] += __shfl_xor(G.b[e], 16);
+        G.b[e] += __shfl_xor(G.b[e], 32);
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) bsm[q * NV + e] = G.b[e];
+    }
+#pragma unroll
+    for (int f = 0; f < NV; ++f) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cr = Mfma<T>::crow(g, r);
+                if (e <= f)
+                    stage[(cr * NV + e) * LD + q] = G.acc[tri_index(e, f, NV)][r];
+                else
+                    stage[(q * NV + e) * LD + cr] = G.acc[tri_index(f, e, NV)][r];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 16; c += VW) {
+            const vec_t t = *reinterpret_cast<const vec_t *>(stage + row * LD + c);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) a[(c + i) * NV + f] = t[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    bb = bsm[row];
+}
+
+// One Gauss-Jordan step: eliminate column P from every other row.  With one row per lane the
+// rows above the pivot are lanes that a triangular factorisation would leave idle, so clearing
+// them too costs no instruction and removes the back substitution.  The trailing block stays
+// the symmetric Schur complement, hence the pivot row's entries A[P][c] are read from column P
+// of lane c.
+template <typename T, int KP, int P>
+struct GjStep {
+    static __device__ __forceinline__ void run(T (&a)[KP], T &bb, T &dinv, int &bad, int lane) {
+        constexpr int BATCH = 8;
+        const T u = a[P];
+        const T d = read_lane(u, P);
+        bad |= (d > T(0)) ? 0 : 1;
+        const T inv = pivot_rcp(d);
+        const T zp = read_lane(bb, P);
+        const bool me = lane == P;
+        const T m = me ? T(0) : u * inv;  // multiplier of this row; the pivot row is kept
+        dinv = me ? inv : dinv;
+        bb -= m * zp;
+#pragma unroll
+        for (int c0 = P + 1; c0 < KP; c0 += BATCH) {
+            T sc[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i)
+                if (c0 + i < KP) sc[i] = read_lane(u, c0 + i);  // A[P][c] = A[c][P]
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i)
+                if (c0 + i < KP) a[c0 + i] -= m * sc[i];
+        }
+        GjStep<T, KP, P + 1>::run(a, bb, dinv, bad, lane);
+    }
+};
+template <typename T, int KP>
+struct GjStep<T, KP, KP> {
+    static __device__ __forceinline__ void run(T (&)[KP], T &, T &, int &, int) {}
+};
+
+// Solve from the accumulators; x_out is the solution component of row `lane`.
+// Returns false when a pivot is not positive.
+template <typename T, int NV>
+__device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int lane, int rank,
+                                         T ridge, T &x_out) {
+    constexpr int KP = NV * 16;
+    add_ridge<T, NV>(G, lane, rank, ridge);
+    T a[KP];
+    T bb;
+    rows_to_regs<T, NV>(G, stage, bsm, lane, a, bb);
+    T dinv = T(1);
+    int bad = 0;  // bitwise, so that no step is skipped through an early-out branch
+    GjStep<T, KP, 0>::run(a, bb, dinv, bad, lane);
+    x_out = bb * dinv;
+    return bad == 0;
+}
 
 // One elimination step of the in-register LDL^T, P known at compile time so that every
 // register index is static (a runtime-indexed row would be demoted to scratch memory).
@@ -364,17 +527,27 @@ struct SolveArgs {
     int64_t row_begin;
 };
 
-// ---- kernel 2: one wave per row — accumulate (or add the row's slabs), assemble, solve -----
+// LDS elements one wave needs: the small transposition stage on the fast path (padded rank
+// <= 64, no dump), the whole matrix otherwise.
+template <typename T, int KP, bool DUMP>
+struct WaveLds {
+    static constexpr bool FAST = !DUMP && KP <= 64;
+    static constexpr int ELEMS = FAST ? Stage<T, KP < 64 ? KP : 64>::ELEMS : Slab<T, KP>::ELEMS;
+    static constexpr size_t BYTES = (size_t)ELEMS * sizeof(T);
+};
+
+// ---- kernel 2: one wave per row — accumulate (or take the row's summed slab), solve ---------
 template <typename T, int NV, int WPB, bool DUMP>
 __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
     constexpr int KP = NV * 16;
     constexpr int LD = Slab<T, KP>::LD;
     constexpr int R = (KP + 63) / 64;
+    constexpr bool FAST = WaveLds<T, KP, DUMP>::FAST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    T *Asm = reinterpret_cast<T *>(smem) + (size_t)wl * Slab<T, KP>::ELEMS;
-    T *bsm = Asm + KP * LD;
+    T *Asm = reinterpret_cast<T *>(smem) + (size_t)wl * WaveLds<T, KP, DUMP>::ELEMS;
+    T *bsm = Asm + KP * (FAST ? Stage<T, KP < 64 ? KP : 64>::LD : LD);
     T *dsm = bsm + KP;
     const int W = gridDim.x * WPB;
     for (int t = blockIdx.x * WPB + wl; t < p.n_tasks; t += W) {
@@ -397,13 +570,18 @@ __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
         G.zero();
         const int sf = p.slab_first[t];
         if (sf >= 0) {
-            const int nch = p.slab_count[t];
-            for (int c = 0; c < nch; ++c)
-                G.add(p.slabs + (size_t)(sf + c) * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
+            // a long row: sum_slabs_kernel left the sum of its chunks in its first slab
+            G.add(p.slabs + (size_t)sf * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
         } else {
             gram_range<T, NV>(G, p.indices, p.vals, p.src, beg, end, lane);
         }
         const T ridge = p.alpha * (T)(end - beg);
+        if constexpr (FAST) {
+            T x;
+            const bool ok = gj_solve<T, NV>(G, Asm, bsm, lane, p.rank, ridge, x);
+            if (lane < KP) out[lane] = ok ? x : T(0);
+            continue;
+        }
         assemble<T, NV>(G, Asm, bsm, lane, p.rank, ridge);
         if constexpr (DUMP) {
             T *Ao = p.A_out + (row - p.row_begin) * (int64_t)KP * KP;
@@ -449,7 +627,8 @@ static size_t slab_slots(int kp) {
 template <typename T, int NV, int WPB>
 static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, hipStream_t st) {
     constexpr int KP = NV * 16;
-    const size_t lds = Slab<T, KP>::BYTES * WPB;
+    const size_t lds =
+        (dump ? WaveLds<T, KP, true>::BYTES : WaveLds<T, KP, false>::BYTES) * WPB;
     int bpc = (int)((160 * 1024) / lds);
     if (bpc < 1) bpc = 1;
     if (bpc * WPB > 16) bpc = 16 / WPB;
@@ -474,6 +653,12 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
         hipLaunchKernelGGL((gram_chunks_kernel<T, NV>), dim3(grid), dim3(256), 0, st, pl->ch_beg,
                            pl->ch_end, pl->n_chunks, indices, static_cast<const T *>(vals),
                            static_cast<const T *>(src), static_cast<T *>(pl->slabs));
+        ALSMI_HIP_CHECK(hipGetLastError());
+        const int slab_elems = Gram<T, NV>::SLAB_SLOTS * WAVE;
+        const int per_row = (slab_elems + 255) / 256;
+        hipLaunchKernelGGL((sum_slabs_kernel<T>), dim3((unsigned)pl->n_heavy * per_row),
+                           dim3(256), 0, st, pl->slab_first, pl->slab_count, pl->n_heavy,
+                           slab_elems, static_cast<T *>(pl->slabs));
         ALSMI_HIP_CHECK(hipGetLastError());
     }
     SolveArgs<T> a;
@@ -511,7 +696,7 @@ static int dispatch(alsmi_plan *pl, const int64_t *indptr, const int32_t *indice
         switch (pl->kp) {
             case 16: ALSMI_CASE(double, 1, 4);
             case 32: ALSMI_CASE(double, 2, 4);
-            case 64: ALSMI_CASE(double, 4, 2);
+            case 64: ALSMI_CASE(double, 4, 4);
             case 128: ALSMI_CASE(double, 8, 1);
         }
     }
