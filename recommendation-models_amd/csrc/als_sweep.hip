@@ -20,6 +20,8 @@
 //   Rows longer than `chunk` entries are cut into chunks; a first kernel writes each chunk's
 //   partial accumulators to a workspace slab and the solve kernel adds the slabs of a row in
 //   chunk order, so results do not depend on how rows are spread over waves or GPUs.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <numeric>
 #include <vector>
@@ -349,9 +351,66 @@ struct GjStep<T, KP, KP> {
     static __device__ __forceinline__ void run(T (&)[KP], T &, T &, int &, int) {}
 };
 
+// Gauss-Jordan step with the pivot row fetched through LDS instead of v_readlane: column P is
+// written once (one element per lane), then every lane reads the entries it needs back with
+// broadcast 16-byte reads — all of a step's reads are issued together, ahead of the arithmetic
+// — and updates two columns per v_pk_fma_f32.  A vector-ALU instruction costs about four
+// cycles of issue here whatever it does, so halving their number is what pays.  Columns <= P
+// are dead after step P (nothing reads them again), so whole aligned groups of four are
+// updated without masking.  `col` is a wave-private LDS vector of KP elements.
+template <int KP, int P, int CH>
+struct GjStepPk {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void run(f2 (&a)[KP / 2], float &bb, float &dinv, int &bad,
+                                               int lane, float *col) {
+        constexpr int G0 = (P + 1) / 4;      // first group of four holding a column > P
+        constexpr int NG = KP / 4 - G0;      // groups to update
+        const float u = a[P / 2][P & 1];
+        if (lane < KP) col[lane] = u;
+        const float d = read_lane(u, P);
+        bad |= (d > 0.0f) ? 0 : 1;
+        const float inv = pivot_rcp(d);
+        const float zp = read_lane(bb, P);
+        const bool me = lane == P;
+        const float m = me ? 0.0f : u * inv;
+        dinv = me ? inv : dinv;
+        bb -= m * zp;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // at most CH groups (4*CH values) of reads in flight, to bound the registers they hold
+        const f2 mm = {-m, -m};
+#pragma unroll
+        for (int h0 = 0; h0 < NG; h0 += CH) {
+            f4 sc[CH];
+#pragma unroll
+            for (int g4 = 0; g4 < CH; ++g4)
+                if (h0 + g4 < NG)
+                    sc[g4] = *reinterpret_cast<const f4 *>(col + 4 * (G0 + h0 + g4));
+#pragma unroll
+            for (int g4 = 0; g4 < CH; ++g4)
+                if (h0 + g4 < NG) {
+                    const int c2 = 2 * (G0 + h0 + g4);
+                    const f2 lo = {sc[g4][0], sc[g4][1]}, hi = {sc[g4][2], sc[g4][3]};
+                    a[c2] = __builtin_elementwise_fma(mm, lo, a[c2]);  // A[P][c] = A[c][P]
+                    a[c2 + 1] = __builtin_elementwise_fma(mm, hi, a[c2 + 1]);
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        GjStepPk<KP, P + 1, CH>::run(a, bb, dinv, bad, lane, col);
+    }
+};
+template <int KP, int CH>
+struct GjStepPk<KP, KP, CH> {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void run(f2 (&)[KP / 2], float &, float &, int &, int,
+                                               float *) {}
+};
+
 // Solve from the accumulators; x_out is the solution component of row `lane`.
 // Returns false when a pivot is not positive.
-template <typename T, int NV>
+template <typename T, int NV, int READS_IN_FLIGHT>
 __device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int lane, int rank,
                                          T ridge, T &x_out) {
     constexpr int KP = NV * 16;
@@ -361,7 +420,15 @@ __device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int l
     rows_to_regs<T, NV>(G, stage, bsm, lane, a, bb);
     T dinv = T(1);
     int bad = 0;  // bitwise, so that no step is skipped through an early-out branch
-    GjStep<T, KP, 0>::run(a, bb, dinv, bad, lane);
+    if constexpr (sizeof(T) == 4) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 a2[KP / 2];
+#pragma unroll
+        for (int c = 0; c < KP / 2; ++c) a2[c] = f2{a[2 * c], a[2 * c + 1]};
+        GjStepPk<KP, 0, READS_IN_FLIGHT>::run(a2, bb, dinv, bad, lane, stage);  // stage is free
+    } else {
+        GjStep<T, KP, 0>::run(a, bb, dinv, bad, lane);
+    }
     x_out = bb * dinv;
     return bad == 0;
 }
@@ -537,7 +604,12 @@ struct WaveLds {
 };
 
 // ---- kernel 2: one wave per row — accumulate (or take the row's summed slab), solve ---------
-template <typename T, int NV, int WPB, bool DUMP>
+// ABLATE selects a diagnostic build used only for timing experiments (env ALSMI_ABLATE, f32
+// rank 64): 1 = accumulate but skip the solve, 2 = solve but skip the accumulation, 3 = eight
+// instead of four broadcast reads in flight per elimination step (more registers, one wave
+// per SIMD fewer).  The
+// production kernel is the ABLATE = 0 instantiation and contains none of that code.
+template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0>
 __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
     constexpr int KP = NV * 16;
     constexpr int LD = Slab<T, KP>::LD;
@@ -572,13 +644,21 @@ __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
         if (sf >= 0) {
             // a long row: sum_slabs_kernel left the sum of its chunks in its first slab
             G.add(p.slabs + (size_t)sf * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
-        } else {
+        } else if constexpr (ABLATE != 2) {
             gram_range<T, NV>(G, p.indices, p.vals, p.src, beg, end, lane);
+        }
+        if constexpr (ABLATE == 1) {
+            T sum = G.b[0];
+#pragma unroll
+            for (int k = 0; k < Gram<T, NV>::NTRI; ++k)
+                sum += G.acc[k][0] + G.acc[k][1] + G.acc[k][2] + G.acc[k][3];
+            if (lane < KP) out[lane] = sum;
+            continue;
         }
         const T ridge = p.alpha * (T)(end - beg);
         if constexpr (FAST) {
             T x;
-            const bool ok = gj_solve<T, NV>(G, Asm, bsm, lane, p.rank, ridge, x);
+            const bool ok = gj_solve<T, NV, ABLATE == 3 ? 8 : 4>(G, Asm, bsm, lane, p.rank, ridge, x);
             if (lane < KP) out[lane] = ok ? x : T(0);
             continue;
         }
@@ -629,16 +709,27 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, hipStre
     constexpr int KP = NV * 16;
     const size_t lds =
         (dump ? WaveLds<T, KP, true>::BYTES : WaveLds<T, KP, false>::BYTES) * WPB;
-    int bpc = (int)((160 * 1024) / lds);
+    auto kern = dump ? solve_rows_kernel<T, NV, WPB, true> : solve_rows_kernel<T, NV, WPB, false>;
+    if constexpr (sizeof(T) == 4 && NV == 4) {
+        static const int ablate = getenv("ALSMI_ABLATE") ? atoi(getenv("ALSMI_ABLATE")) : 0;
+        if (!dump && ablate == 1) kern = solve_rows_kernel<T, NV, WPB, false, 1>;
+        if (!dump && ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
+        if (!dump && ablate == 3) kern = solve_rows_kernel<T, NV, WPB, false, 3>;
+    }
+    ALSMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // Rows are dealt to waves round-robin over the degree-sorted order, which balances the
+    // load only if every wave of the grid is resident at once: size the grid to what the
+    // registers and the LDS of this instantiation admit per CU.  (Waves never wait on each
+    // other, so an over-estimate costs time, not correctness.)
+    int bpc = 0;
+    ALSMI_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &bpc, reinterpret_cast<const void *>(kern), WPB * 64, lds));
     if (bpc < 1) bpc = 1;
-    if (bpc * WPB > 16) bpc = 16 / WPB;
     int grid = pl->cu_count * bpc;
     const int need = (pl->n_tasks + WPB - 1) / WPB;
     if (grid > need) grid = need;
     if (grid < 1) return ALSMI_OK;
-    auto kern = dump ? solve_rows_kernel<T, NV, WPB, true> : solve_rows_kernel<T, NV, WPB, false>;
-    ALSMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), lds, st, a);
     ALSMI_HIP_CHECK(hipGetLastError());
     return ALSMI_OK;
