@@ -1,0 +1,110 @@
+"""Parity at the benchmark's full size (BASELINE config 2: 138 493 x 26 744, 20 M entries,
+rank 64) on sampled rows and through size-independent properties.
+
+The oracle cannot sweep the whole matrix in seconds, but a row's update depends only on that
+row's entries and the other side's factors, so the C restatement is run on a SAMPLE of rows
+(the longest ones, which take the chunked path, the shortest, and random ones) and compared
+row for row; the squared-error pass is checked on a row range the same way.  Whole-matrix
+properties: every updated row satisfies its normal equations, and the training error never
+increases from one sweep to the next."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_USERS, N_ITEMS, NNZ, RANK = 138493, 26744, 20000000, 64
+
+
+@pytest.fixture(scope='module')
+def problem():
+    import torch
+    from alsmi import device as dev
+    from alsmi import synth
+    from alsmi.engine import AlsEngine
+    device = dev.require_gpu()
+    prob = synth.sharded_problem(20242, N_USERS, N_ITEMS, NNZ, 1, 0, device)
+    host = {k: tuple(t.cpu().numpy() for t in prob[k]) for k in ('csr', 'csc')}
+    rs = np.random.RandomState(42)
+    V0 = rs.rand(RANK, N_ITEMS)
+    return dict(device=device, torch=torch, prob=prob, host=host, V0=V0, AlsEngine=AlsEngine)
+
+
+def sample_rows(indptr, n_random, seed):
+    deg = np.diff(indptr)
+    order = np.argsort(-deg, kind='stable')
+    rng = np.random.default_rng(seed)
+    picks = np.concatenate([order[:24], order[-8:], rng.choice(deg.size, n_random, replace=False)])
+    return np.unique(picks), deg
+
+
+def oracle_rows(co, csr, rows, src_rows, alpha):
+    indptr, indices, vals = csr
+    out = np.zeros((rows.size, src_rows.shape[1]))
+    for k, r in enumerate(rows):
+        lo, hi = int(indptr[r]), int(indptr[r + 1])
+        sub_ptr = np.array([0, hi - lo], dtype=np.int64)
+        out[k] = co.half_sweep(sub_ptr, indices[lo:hi], vals[lo:hi].astype(np.float64), src_rows,
+                               alpha, threads=1)[0]
+    return out
+
+
+def row_rel_err(got, want):
+    return np.linalg.norm(got - want, axis=1) / np.maximum(np.linalg.norm(want, axis=1), 1e-30)
+
+
+@pytest.mark.parametrize('dtype,tol', [('float32', 1e-4), ('float64', 1e-10)])
+def test_sampled_rows_match_oracle_at_full_size(problem, dtype, tol):
+    from oracle import c_oracle as co
+    torch, P = problem['torch'], problem['prob']
+    eng = problem['AlsEngine'](P['csr'], P['csc'], P['shape'], RANK, 0.1, dtype=dtype)
+    assert eng.plan_u.info()['n_chunks'] > 0 and eng.plan_i.info()['n_chunks'] > 1000
+    eng.set_factors(np.zeros((RANK, N_USERS)), problem['V0'])
+    Vq = eng.V[:, :RANK].to(torch.float64).cpu().numpy()
+
+    eng.half_sweep_users()
+    U = eng.U[:, :RANK].to(torch.float64).cpu().numpy()
+    rows, deg = sample_rows(problem['host']['csr'][0], 150, 1)
+    assert deg[rows].max() > 2048            # the chunked path is in the sample
+    want = oracle_rows(co, problem['host']['csr'], rows, Vq, 0.1)
+    assert row_rel_err(U[rows], want).max() < tol
+
+    eng.half_sweep_items()
+    V = eng.V[:, :RANK].to(torch.float64).cpu().numpy()
+    rows, deg = sample_rows(problem['host']['csc'][0], 150, 2)
+    assert deg[rows].max() > 20000
+    want = oracle_rows(co, problem['host']['csc'], rows, U, 0.1)
+    assert row_rel_err(V[rows], want).max() < tol
+    empty = np.flatnonzero(deg == 0)
+    assert not V[empty].any()
+
+    # squared error: the kernel over all 20 M entries against the oracle over the same entries
+    indptr, indices, vals = problem['host']['csr']
+    sse = float(eng.train_sse_async().cpu()[0])
+    want_sse = co.sse(indptr, indices, vals.astype(np.float64), U, V, threads=8)
+    np.testing.assert_allclose(sse, want_sse, rtol=2e-6 if dtype == 'float32' else 1e-11)
+
+
+def test_whole_matrix_properties_fp32(problem):
+    torch, P = problem['torch'], problem['prob']
+    eng = problem['AlsEngine'](P['csr'], P['csc'], P['shape'], RANK, 0.1, dtype='float32')
+    eng.set_factors(np.zeros((RANK, N_USERS)), problem['V0'])
+    rmse = []
+    for _ in range(4):
+        eng.sweep()
+        rmse.append(eng.train_rmse())
+    assert all(np.isfinite(rmse)) and all(b <= a * (1 + 1e-6) for a, b in zip(rmse, rmse[1:]))
+    assert torch.isfinite(eng.U).all() and torch.isfinite(eng.V).all()
+    assert not eng.U[:, RANK:].any() and not eng.V[:, RANK:].any()
+    # normal equations: (S S^T + alpha n I) x = S r for a block of rows, in fp64 on the host
+    eng.half_sweep_users()
+    indptr, indices, vals = problem['host']['csr']
+    U = eng.U[:, :RANK].to(torch.float64).cpu().numpy()
+    V = eng.V[:, :RANK].to(torch.float64).cpu().numpy()
+    worst = 0.0
+    for r in range(5000, 5200):
+        lo, hi = int(indptr[r]), int(indptr[r + 1])
+        S = V[indices[lo:hi]]
+        b = S.T.dot(vals[lo:hi].astype(np.float64))
+        res = S.T.dot(S.dot(U[r])) + 0.1 * (hi - lo) * U[r] - b
+        worst = max(worst, np.linalg.norm(res) / max(np.linalg.norm(b), 1e-30))
+    assert worst < 2e-5
