@@ -133,13 +133,16 @@ class AlsEngine(object):
 
     # ---- collectives --------------------------------------------------------
     def _all_gather_rows(self, table, bounds):
+        """Every rank contributes rows [bounds[r], bounds[r+1]) of `table`; afterwards all
+        ranks hold the whole table.  The send buffer never aliases the receive buffer."""
         if self.world == 1:
             return
         import torch.distributed as dist
         sizes = np.diff(bounds)
         lo, hi = int(bounds[self.me]), int(bounds[self.me + 1])
         if sizes.min() == sizes.max():
-            dist.all_gather_into_tensor(table, table[lo:hi], group=self.group)
+            send = table[lo:hi].clone()
+            dist.all_gather_into_tensor(table, send, group=self.group)
             return
         width = int(sizes.max())
         send = torch.zeros((width, table.shape[1]), dtype=table.dtype, device=table.device)
