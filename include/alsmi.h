@@ -107,6 +107,28 @@ int alsmi_sddmm(int dtype, int rank, int64_t n_pairs, const int32_t *users,
 int alsmi_expand_rows(const int64_t *indptr, int64_t row_begin, int64_t row_end,
                       int32_t *rows_out, void *stream);
 
+/* ---- sparse structure on the device: src/als.py:137-140 (triplets -> lil -> CSR)
+ * and src/als.py:268-280 (scipy's csr_tocsc, which the reference re-runs per item) --
+ *
+ * alsmi_build_csr: n_in triplets (users, items int32; vals always fp64, the
+ * reference's y) of an n_rows x n_cols matrix.  Same result as the reference's
+ * element-by-element fill: a position written more than once keeps the LAST
+ * value, a final value of exactly 0 is not stored, column indices inside a row
+ * are sorted.  Outputs: indptr [n_rows+1], indices and vals_out (dtype) with
+ * room for n_in entries, nnz_out[0] (device) = number stored.
+ * alsmi_csr_to_csc: entries ordered by column, row ids ascending inside a
+ * column (bit-identical to scipy's csr_tocsc); cptr [n_cols+1], cidx/cvals [nnz].
+ * workspace: alsmi_sparse_workspace_bytes(number of input entries) bytes
+ * (0 is returned when no HIP device is present to size it). */
+size_t alsmi_sparse_workspace_bytes(int64_t n_entries);
+int alsmi_build_csr(int dtype, int64_t n_rows, int64_t n_cols, int64_t n_in,
+                    const int32_t *users, const int32_t *items, const double *vals,
+                    int64_t *indptr, int32_t *indices, void *vals_out, int64_t *nnz_out,
+                    void *workspace, void *stream);
+int alsmi_csr_to_csc(int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                     const int64_t *indptr, const int32_t *indices, const void *vals,
+                     int64_t *cptr, int32_t *cidx, void *cvals, void *workspace, void *stream);
+
 /* ---- IMC objective pieces: src/imc.py:43-48 (_cost), :65-71 (_cost_prime),
  * :91-96 (_cost_hess), :157 (initial Z) ------------------------------------
  *

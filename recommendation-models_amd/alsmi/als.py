@@ -16,7 +16,7 @@ from sklearn.utils.validation import check_is_fitted, check_random_state
 
 from . import device as dev
 from .engine import AlsEngine
-from .utils import (_check_x, _check_y, root_mean_squared_error, triplets_to_csr)
+from .utils import _check_x, _check_y, root_mean_squared_error
 
 
 def _default_group():
@@ -70,8 +70,11 @@ class ALS(BaseEstimator):
                              'provided.')
         users, items = _check_x(X)
         if not sps.issparse(y):
-            indptr, indices, vals = triplets_to_csr(users, items, y, shape)
-            data = sps.csr_matrix((vals, indices, indptr), shape=tuple(shape))
+            # triplets -> CSR on the device (last write wins, zeros dropped, sorted columns)
+            indptr, indices, vals = dev.build_csr(users, items, y, shape, np.float64,
+                                                  dev.require_gpu())
+            data = sps.csr_matrix((vals.cpu().numpy(), indices.cpu().numpy(),
+                                   indptr.cpu().numpy()), shape=tuple(int(v) for v in shape))
         else:
             data = y.tocsr().astype(np.float64)
             if data is y:

@@ -202,3 +202,70 @@ def sddmm(rank, users, items, row_table, col_table, vals=None, want_pred=True):
                                _ptr(pred), _ptr(sse), _ptr(_sddmm_workspace(device)), _stream()),
                'alsmi_sddmm')
     return pred, sse
+
+
+_sparse_ws = {}
+
+
+def _sparse_workspace(n_entries, device):
+    """Grow-only workspace for the structure builders (one per device)."""
+    lib = _lib.load()
+    need = int(lib.alsmi_sparse_workspace_bytes(int(n_entries)))
+    if need == 0:
+        raise RuntimeError('alsmi_sparse_workspace_bytes failed (no HIP device, or too many '
+                           'entries: %d)' % n_entries)
+    key = (device.type, device.index)
+    ws = _sparse_ws.get(key)
+    if ws is None or ws.numel() * 8 < need:
+        ws = torch.empty(need // 8 + 1, dtype=torch.float64, device=device)
+        _sparse_ws[key] = ws
+    return ws
+
+
+def build_csr(users, items, y, shape, dtype, device):
+    """Ratings triplets -> CSR on the device, with the reference's lil-fill semantics
+    (src/als.py:137-140).  users/items/y are host arrays.  Returns device tensors
+    (indptr int64 [n+1], indices int32 [nnz], vals dtype [nnz])."""
+    n, m = int(shape[0]), int(shape[1])
+    users = np.asarray(users).ravel()
+    items = np.asarray(items).ravel()
+    y = np.asarray(y, dtype=np.float64).ravel()
+    if not (users.size == items.size == y.size):
+        raise ValueError('users, items and y must have the same length')
+    if users.size and (users.min() < -n or users.max() >= n or
+                       items.min() < -m or items.max() >= m):
+        raise IndexError('index out of bounds for shape {}'.format((n, m)))
+    users = np.where(users < 0, users + n, users).astype(np.int32)
+    items = np.where(items < 0, items + m, items).astype(np.int32)
+    n_in = int(users.size)
+    td = torch_dtype(dtype)
+    d_users = torch.from_numpy(users).to(device)
+    d_items = torch.from_numpy(items).to(device)
+    d_y = torch.from_numpy(y).to(device)
+    indptr = torch.empty(n + 1, dtype=torch.int64, device=device)
+    indices = torch.empty(max(n_in, 1), dtype=torch.int32, device=device)
+    vals = torch.empty(max(n_in, 1), dtype=td, device=device)
+    nnz = torch.zeros(1, dtype=torch.int64, device=device)
+    ws = _sparse_workspace(n_in, device)
+    _lib.check(_lib.load().alsmi_build_csr(
+        _lib.dtype_code(dtype), n, m, n_in, _ptr(d_users), _ptr(d_items), _ptr(d_y), _ptr(indptr),
+        _ptr(indices), _ptr(vals), _ptr(nnz), _ptr(ws), _stream()), 'alsmi_build_csr')
+    count = int(nnz.cpu()[0])
+    return indptr, indices[:count].contiguous(), vals[:count].contiguous()
+
+
+def csr_to_csc(indptr, indices, vals, shape):
+    """Device CSR -> device CSC (the CSR of the transpose), bit-identical to scipy's
+    csr_tocsc (src/als.py:275-279)."""
+    n, m = int(shape[0]), int(shape[1])
+    device = indptr.device
+    nnz = int(indices.numel())
+    dtype = np.float32 if vals.dtype == torch.float32 else np.float64
+    cptr = torch.empty(m + 1, dtype=torch.int64, device=device)
+    cidx = torch.empty(nnz, dtype=torch.int32, device=device)
+    cvals = torch.empty(nnz, dtype=vals.dtype, device=device)
+    ws = _sparse_workspace(nnz, device)
+    _lib.check(_lib.load().alsmi_csr_to_csc(
+        _lib.dtype_code(dtype), n, m, nnz, _ptr(indptr), _ptr(indices), _ptr(vals), _ptr(cptr),
+        _ptr(cidx), _ptr(cvals), _ptr(ws), _stream()), 'alsmi_csr_to_csc')
+    return cptr, cidx, cvals

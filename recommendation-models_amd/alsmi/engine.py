@@ -9,7 +9,6 @@ xGMI when the backend is "nccl"), the training error with an all-reduce of the
 squared-error sum.
 """
 import numpy as np
-import scipy.sparse as sps
 import torch
 
 from . import device as dev
@@ -47,6 +46,14 @@ class LocalBackend(object):
 
     def padded_rank(self, rank):
         return dev.padded_rank(rank)
+
+    def csr_to_csc(self, indptr, indices, vals, shape, dtype):
+        """CSR (host or device arrays) -> (csr, csc) triples of device tensors."""
+        td = dev.torch_dtype(dtype)
+        d_ptr = dev._as_device(indptr, torch.int64, self.device)
+        d_idx = dev._as_device(indices, torch.int32, self.device)
+        d_val = dev._as_device(vals, td, self.device)
+        return (d_ptr, d_idx, d_val), dev.csr_to_csc(d_ptr, d_idx, d_val, shape)
 
 
 class AlsEngine(object):
@@ -99,26 +106,28 @@ class AlsEngine(object):
     @classmethod
     def from_global(cls, indptr, indices, vals, shape, rank, alpha, dtype=np.float64,
                     group=None, backend=None, chunk=0):
-        """Every rank holds the whole CSR on the host; cut it into per-rank ranges
-        balanced by stored entries and keep the local slices."""
+        """Every rank is given the whole CSR (host arrays or device tensors).  The CSC is
+        built on the device (the reference re-runs scipy's csr_tocsc per item,
+        src/als.py:268-280), both are cut into per-rank row ranges balanced by stored
+        entries and only the local slices are kept."""
+        backend = backend if backend is not None else LocalBackend()
         n, m = int(shape[0]), int(shape[1])
         if group is not None:
             import torch.distributed as dist
             world, me = dist.get_world_size(group), dist.get_rank(group)
         else:
             world, me = 1, 0
-        indptr = np.asarray(indptr, dtype=np.int64)
-        mat = sps.csr_matrix((np.asarray(vals), np.asarray(indices), indptr),
-                             shape=(n, m)).tocsc()
-        mat.sort_indices()
-        cptr, cidx, cvals = mat.indptr.astype(np.int64), mat.indices, mat.data
-        ub, ib = split_by_nnz(indptr, world), split_by_nnz(cptr, world)
-        a, z = int(indptr[ub[me]]), int(indptr[ub[me + 1]])
-        csr = (indptr[ub[me]:ub[me + 1] + 1] - a, indices[a:z], vals[a:z])
-        a, z = int(cptr[ib[me]]), int(cptr[ib[me + 1]])
-        csc = (cptr[ib[me]:ib[me + 1] + 1] - a, cidx[a:z], cvals[a:z])
+        (ptr, idx, val), (cptr, cidx, cval) = backend.csr_to_csc(indptr, indices, vals, (n, m),
+                                                                 dtype)
+        ptr_h = ptr.cpu().numpy() if torch.is_tensor(ptr) else np.asarray(ptr, dtype=np.int64)
+        cptr_h = cptr.cpu().numpy() if torch.is_tensor(cptr) else np.asarray(cptr, dtype=np.int64)
+        ub, ib = split_by_nnz(ptr_h, world), split_by_nnz(cptr_h, world)
+        a, z = int(ptr_h[ub[me]]), int(ptr_h[ub[me + 1]])
+        csr = (ptr_h[ub[me]:ub[me + 1] + 1] - a, idx[a:z], val[a:z])
+        a, z = int(cptr_h[ib[me]]), int(cptr_h[ib[me + 1]])
+        csc = (cptr_h[ib[me]:ib[me + 1] + 1] - a, cidx[a:z], cval[a:z])
         return cls(csr, csc, (n, m), rank, alpha, dtype=dtype, user_bounds=ub, item_bounds=ib,
-                   group=group, backend=backend, chunk=chunk, total_nnz=int(indptr[-1]))
+                   group=group, backend=backend, chunk=chunk, total_nnz=int(ptr_h[-1]))
 
     # ---- factors ------------------------------------------------------------
     def set_factors(self, user_feats, item_feats):

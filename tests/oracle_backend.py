@@ -5,6 +5,7 @@ never constructs it."""
 import numpy as np
 import torch
 
+from oracle import als_oracle as ao
 from oracle import c_oracle as co
 
 
@@ -50,6 +51,13 @@ class OracleBackend(object):
 
     def padded_rank(self, rank):
         return 16 if rank <= 16 else 32 if rank <= 32 else 64 if rank <= 64 else 128
+
+    def csr_to_csc(self, indptr, indices, vals, shape, dtype):
+        indptr = np.asarray(indptr, dtype=np.int64)
+        indices = np.asarray(indices, dtype=np.int32)
+        vals = np.asarray(vals, dtype=np.float64)
+        cptr, cidx, cvals = ao.csr_to_csc(int(shape[0]), int(shape[1]), indptr, indices, vals)
+        return (indptr, indices, vals), (cptr, cidx, cvals)
 
     def sddmm(self, rank, users, items, row_table, col_table, vals, want_pred):
         u = row_table[users.long(), :rank]
