@@ -150,8 +150,149 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, const int32_t *__rest
     }
 }
 
+// ---- fp32 Gram build on the bf16 matrix cores (exact three-way split) -------------------------
+// The fp32 MFMA runs at the vector-ALU rate and does not overlap with vector work; the bf16 MFMA
+// is sixteen times faster per element.  An fp32 value is EXACTLY the sum of three bf16 values
+// x = h + m + l (8 + 8 + 8 significant bits, obtained by truncation and exact subtraction), and
+// x*y = hh' + hm' + mh' + hl' + lh' + mm' up to terms of relative size 2^-24, each product being
+// exact in the fp32 accumulator.  Six v_mfma_f32_16x16x32_bf16 (16 cycles, 32 neighbours each)
+// replace eight v_mfma_f32_16x16x4_f32 (32 cycles, 4 neighbours each) per tile: 96 against 256
+// cycles, at fp32-equivalent accuracy.
+// Operand map of 16x16x32: lane (g,q) holds A[row q][k = 8g + j], j = 0..7.  Load step j of lane
+// group g therefore fetches neighbour 8g + j (still four whole rows per wave instruction), and
+// the eight loaded registers of column class e ARE the operand — no transpose.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned hi16_pair(unsigned lo_elem, unsigned hi_elem) {
+    return (lo_elem >> 16) | (hi_elem & 0xffff0000u);  // bf16 of element 2i | element 2i+1
+}
+
+// 32 neighbours, at entries off .. off+31 of the wave's 64-entry index block; `valid` of them
+// exist (FULL: all 32).
+template <int NV, bool FULL>
+__device__ __forceinline__ void gram_block32_split(Gram<float, NV> &G,
+                                                   const float *__restrict__ srcq, int idx,
+                                                   float rv, int off, int valid, int g) {
+    constexpr int KP = NV * 16;
+    float v[8][NV];
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 8 * g + j;
+        const int id = __shfl(idx, off + t);
+        r[j] = __shfl(rv, off + t);
+        load_vec<float, NV>(v[j], srcq + (int64_t)id * KP);
+        if constexpr (!FULL) {
+            const bool ok = t < valid;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) v[j][e] = ok ? v[j][e] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) G.b[e] += r[j] * v[j][e];
+    bf16x8 H[NV], M[NV], L[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[j][e];
+            const unsigned xb = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+            const float r1 = x - __builtin_bit_cast(float, xb);  // exact
+            const unsigned rb = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, rb);  // exact, <= 8 significant bits
+            hb[j] = xb;
+            mb[j] = rb;
+            lb[j] = __builtin_bit_cast(unsigned, r2);
+        }
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ph[i] = hi16_pair(hb[2 * i], hb[2 * i + 1]);
+            pm[i] = hi16_pair(mb[2 * i], mb[2 * i + 1]);
+            pl[i] = hi16_pair(lb[2 * i], lb[2 * i + 1]);
+        }
+        H[e] = __builtin_bit_cast(bf16x8, ph);
+        M[e] = __builtin_bit_cast(bf16x8, pm);
+        L[e] = __builtin_bit_cast(bf16x8, pl);
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = e; f < NV; ++f) {
+            Mfma<float>::acc_t c = G.acc[tri_index(e, f, NV)];
+            // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(M[e], M[f], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H[e], L[f], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(L[e], H[f], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H[e], M[f], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(M[e], H[f], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H[e], H[f], c, 0, 0, 0);
+            G.acc[tri_index(e, f, NV)] = c;
+        }
+}
+
+// Accumulate entries [beg, end) of one row on the bf16 matrix cores (fp32 data).
+template <int NV>
+__device__ __forceinline__ void gram_range_split(Gram<float, NV> &G,
+                                                 const int32_t *__restrict__ indices,
+                                                 const float *__restrict__ vals,
+                                                 const float *__restrict__ src, int64_t beg,
+                                                 int64_t end, int lane) {
+    const int g = lane >> 4, q = lane & 15;
+    const float *srcq = src + q * NV;
+    int idx_n = 0;
+    float rv_n = 0.0f;
+    if (beg + lane < end) {
+        idx_n = indices[beg + lane];
+        rv_n = vals[beg + lane];
+    }
+    for (int64_t base = beg; base < end; base += WAVE) {
+        const int64_t left = end - base;
+        const int cnt = left < WAVE ? (int)left : WAVE;
+        const int idx = idx_n;
+        const float rv = rv_n;
+        idx_n = 0;
+        rv_n = 0.0f;
+        if (base + WAVE + lane < end) {
+            idx_n = indices[base + WAVE + lane];
+            rv_n = vals[base + WAVE + lane];
+        }
+        if (cnt >= 32)
+            gram_block32_split<NV, true>(G, srcq, idx, rv, 0, 32, g);
+        else
+            gram_block32_split<NV, false>(G, srcq, idx, rv, 0, cnt, g);
+        if (cnt == 64)
+            gram_block32_split<NV, true>(G, srcq, idx, rv, 32, 32, g);
+        else if (cnt > 32)
+            gram_block32_split<NV, false>(G, srcq, idx, rv, 32, cnt - 32, g);
+    }
+}
+
+// Which accumulation an instantiation uses: fp32 data up to padded rank 64 goes to the bf16
+// matrix cores; fp64 keeps its own MFMA, and so does fp32 at padded rank 128, where the three
+// operand sets next to 36 accumulator tiles no longer fit the register file.  FP32_MFMA forces
+// the fp32 MFMA (timing comparisons).
+template <typename T, int NV, bool FP32_MFMA>
+constexpr bool use_split() {
+    return sizeof(T) == 4 && NV <= 4 && !FP32_MFMA;
+}
+
+template <typename T, int NV, bool SPLIT>
+__device__ __forceinline__ void gram_accumulate(Gram<T, NV> &G, const int32_t *indices,
+                                                const T *vals, const T *src, int64_t beg,
+                                                int64_t end, int lane) {
+    if constexpr (SPLIT && sizeof(T) == 4)
+        gram_range_split<NV>(G, indices, vals, src, beg, end, lane);
+    else
+        gram_range<T, NV>(G, indices, vals, src, beg, end, lane);
+}
+
 // ---- kernel 1: partial normal equations of the chunks of long rows ---------------------
-template <typename T, int NV>
+template <typename T, int NV, bool FP32_MFMA = false>
 __global__ __launch_bounds__(256) void gram_chunks_kernel(
     const int64_t *__restrict__ ch_beg, const int64_t *__restrict__ ch_end, int n_chunks,
     const int32_t *__restrict__ indices, const T *__restrict__ vals, const T *__restrict__ src,
@@ -161,7 +302,8 @@ __global__ __launch_bounds__(256) void gram_chunks_kernel(
     if (w >= n_chunks) return;
     Gram<T, NV> G;
     G.zero();
-    gram_range<T, NV>(G, indices, vals, src, ch_beg[w], ch_end[w], lane);
+    gram_accumulate<T, NV, use_split<T, NV, FP32_MFMA>()>(G, indices, vals, src, ch_beg[w],
+                                                          ch_end[w], lane);
     G.store(slabs + (size_t)w * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
 }
 
@@ -607,7 +749,7 @@ struct WaveLds {
 // ABLATE selects a diagnostic build used only for timing experiments (env ALSMI_ABLATE, f32
 // rank 64): 1 = accumulate but skip the solve, 2 = solve but skip the accumulation, 3 = eight
 // instead of four broadcast reads in flight per elimination step (more registers, one wave
-// per SIMD fewer).  The
+// per SIMD fewer), 4 = Gram build on the fp32 MFMA instead of the bf16 matrix cores (both kernels).  The
 // production kernel is the ABLATE = 0 instantiation and contains none of that code.
 template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0>
 __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
@@ -645,7 +787,8 @@ __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
             // a long row: sum_slabs_kernel left the sum of its chunks in its first slab
             G.add(p.slabs + (size_t)sf * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
         } else if constexpr (ABLATE != 2) {
-            gram_range<T, NV>(G, p.indices, p.vals, p.src, beg, end, lane);
+            gram_accumulate<T, NV, use_split<T, NV, ABLATE == 4>()>(G, p.indices, p.vals, p.src,
+                                                                    beg, end, lane);
         }
         if constexpr (ABLATE == 1) {
             T sum = G.b[0];
@@ -715,6 +858,7 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, hipStre
         if (!dump && ablate == 1) kern = solve_rows_kernel<T, NV, WPB, false, 1>;
         if (!dump && ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
         if (!dump && ablate == 3) kern = solve_rows_kernel<T, NV, WPB, false, 3>;
+        if (!dump && ablate == 4) kern = solve_rows_kernel<T, NV, WPB, false, 4>;
     }
     ALSMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -741,8 +885,13 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
                           void *b_out, hipStream_t st) {
     if (pl->n_chunks > 0) {
         const int grid = (pl->n_chunks + 3) / 4;
-        hipLaunchKernelGGL((gram_chunks_kernel<T, NV>), dim3(grid), dim3(256), 0, st, pl->ch_beg,
-                           pl->ch_end, pl->n_chunks, indices, static_cast<const T *>(vals),
+        auto chunks = gram_chunks_kernel<T, NV, false>;
+        if constexpr (sizeof(T) == 4 && NV == 4) {
+            static const int ablate = getenv("ALSMI_ABLATE") ? atoi(getenv("ALSMI_ABLATE")) : 0;
+            if (ablate == 4) chunks = gram_chunks_kernel<T, NV, true>;
+        }
+        hipLaunchKernelGGL(chunks, dim3(grid), dim3(256), 0, st, pl->ch_beg, pl->ch_end,
+                           pl->n_chunks, indices, static_cast<const T *>(vals),
                            static_cast<const T *>(src), static_cast<T *>(pl->slabs));
         ALSMI_HIP_CHECK(hipGetLastError());
         const int slab_elems = Gram<T, NV>::SLAB_SLOTS * WAVE;
