@@ -6,6 +6,10 @@
 
 One step = one ALS sweep: user half-sweep, item half-sweep, training squared error over
 all stored entries (what one iteration of the reference's loop does, src/als.py:154-167).
+The squared error of a sweep is produced by the user half of the NEXT step, which reads
+the same ratings and item factors anyway (the schedule ALS.fit uses); the error of the last
+timed sweep is a standalone pass inside the timed region, so K timed steps contain K user
+halves, K item halves and K+1 error sums.
 With N ranks the problem is N user blocks of the single-GPU size (weak scaling): every
 rank updates its own users and its slice of the items, each half-sweep ends with an
 all-gather of the updated factor rows.  Inputs are resident in HBM before the timed
@@ -88,6 +92,9 @@ def main():
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--dtype', default='float32', choices=['float32', 'float64'])
     ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--separate-error', action='store_true',
+                    help='compute the training error in its own pass after every sweep '
+                         'instead of inside the next user half-sweep (A/B aid)')
     ap.add_argument('--cpu-frac', type=float, default=0.25,
                     help='fraction of rows the CPU baseline is timed on (0 disables it)')
     args = ap.parse_args()
@@ -142,22 +149,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fused = not args.separate_error
     sse_log = []
-    for _ in range(args.warmup):
-        engine.half_sweep_users()
+
+    def step(events=None):
+        if events:
+            events[0].record()
+        if fused:
+            sse_log.append(engine.half_sweep_users_err())  # error of the state before
+        else:
+            engine.half_sweep_users()
+        if events:
+            events[1].record()
         engine.half_sweep_items()
-        sse_log.append(engine.train_sse_async())
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        if events:
+            events[2].record()
+        if not fused:
+            sse_log.append(engine.train_sse_async())
+
+    for _ in range(args.warmup):
+        step()
+    engine.train_sse_async()  # untimed: first-use set-up of the standalone error pass
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    ev_tail = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        ev[s][0].record()
-        engine.half_sweep_users()
-        ev[s][1].record()
-        engine.half_sweep_items()
-        ev[s][2].record()
-        sse_log.append(engine.train_sse_async())
-        ev[s][3].record()
+        step(ev[s])
+    ev_tail[0].record()
+    if fused:
+        sse_log.append(engine.train_sse_async())  # error of the last timed sweep
+    ev_tail[1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -169,12 +191,14 @@ def main():
     rmse = [float(np.sqrt(float(x.cpu()[0]) / engine.nnz)) for x in sse_log]
     t_user = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)])) * 1e-3
     t_item = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(args.steps)])) * 1e-3
-    t_sse = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in range(args.steps)])) * 1e-3
+    t_sse = ev_tail[0].elapsed_time(ev_tail[1]) * 1e-3 if fused else None
 
     if rank_id == 0:
         s = 4 if args.dtype == 'float32' else 8
         kp = engine.kp
         b_user = half_sweep_bytes(engine.csr.nnz, engine.csr.n_rows, kp, s)
+        if fused:
+            b_user += engine.csr.n_rows * kp * s  # the replaced vectors are read for the error
         b_item = half_sweep_bytes(engine.csc.nnz, engine.csc.n_rows, kp, s)
         b_sse = sddmm_bytes(engine.csr.nnz, engine.csr.n_rows, kp, s)
         achieved = (b_user + b_item) / (t_user + t_item) / 1e9
@@ -208,8 +232,11 @@ def main():
                 'user_side': {'ms': t_user * 1e3, 'GBps': b_user / t_user / 1e9},
                 'item_side': {'ms': t_item * 1e3, 'GBps': b_item / t_item / 1e9},
             },
-            'sddmm': {'ms': t_sse * 1e3, 'GBps': b_sse / t_sse / 1e9,
-                      'frac': b_sse / t_sse / 1e9 / HBM_PEAK_GBS},
+            'error_pass': ({'schedule': 'fused into the next user half-sweep; one standalone '
+                                        'pass after the last timed sweep',
+                            'standalone_ms': t_sse * 1e3,
+                            'standalone_GBps': b_sse / t_sse / 1e9} if fused else
+                           {'schedule': 'standalone pass after every sweep'}),
             'train_rmse': {'first': rmse[0] if rmse else None, 'last': rmse[-1] if rmse else None},
             'setup_s': {'generate': t_gen},
         }

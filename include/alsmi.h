@@ -82,6 +82,18 @@ int alsmi_half_sweep(alsmi_plan *plan, const int64_t *indptr, const int32_t *ind
                      const void *vals, const void *src_factors, int64_t n_src,
                      void *dst_factors, double alpha, void *stream);
 
+/* The same half-sweep, which also returns the squared training error of the factors it
+ * REPLACES: sse_out[0] (one double, device) = sum over the stored entries t of the plan's
+ * rows of (vals_t - <cur_factors[r], f_t>)^2, the quantity the reference computes in a
+ * separate pass after every sweep (src/als.py:161-165).  The kernels read every f_t anyway,
+ * so the error of sweep s comes for free with the user half of sweep s+1.  cur_factors is
+ * indexed like dst_factors and may be the same table (a row is read before it is
+ * written).  Partial sums are combined in a fixed order. */
+int alsmi_half_sweep_err(alsmi_plan *plan, const int64_t *indptr, const int32_t *indices,
+                         const void *vals, const void *src_factors, int64_t n_src,
+                         const void *cur_factors, void *dst_factors, double alpha,
+                         double *sse_out, void *stream);
+
 /* Debug / test aid: the assembled normal equations of the plan's rows before the
  * solve.  A_out [n_rows x ld x ld], b_out [n_rows x ld], both indexed by
  * (row - row_begin), natural (unpermuted) order, ridge included. */

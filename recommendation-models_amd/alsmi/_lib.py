@@ -41,6 +41,8 @@ def load():
         'alsmi_plan_info': (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
                                     ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
         'alsmi_half_sweep': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_dbl, c_vp]),
+        'alsmi_half_sweep_err': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_dbl,
+                                         c_vp, c_vp]),
         'alsmi_normal_equations': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_dbl,
                                            c_vp]),
         'alsmi_sddmm_workspace_bytes': (ctypes.c_size_t, []),
@@ -67,6 +69,7 @@ def load():
 
 EXPORTS = ('alsmi_version', 'alsmi_last_error', 'alsmi_padded_rank', 'alsmi_plan_create',
            'alsmi_plan_destroy', 'alsmi_plan_info', 'alsmi_half_sweep',
+           'alsmi_half_sweep_err',
            'alsmi_normal_equations', 'alsmi_sddmm_workspace_bytes', 'alsmi_sddmm',
            'alsmi_expand_rows', 'alsmi_sparse_workspace_bytes', 'alsmi_build_csr',
            'alsmi_csr_to_csc', 'alsmi_imc_padded_width', 'alsmi_imc_workspace_bytes',

@@ -108,22 +108,48 @@ class ALS(BaseEstimator):
         engine = AlsEngine.from_global(data.indptr, data.indices, data.data, (n, m), self.rank,
                                        self.alpha, dtype=self.dtype, group=_default_group())
         engine.set_factors(self.user_feats, self.item_feats)
+        # The error of sweep s is produced by the user half of sweep s+1, which reads the
+        # same ratings and item factors anyway; its new user rows stay parked until the
+        # stopping rule (src/als.py:154, 161-167) has seen that error, so stopping returns
+        # exactly the factors of sweep s as the reference does.
         rmse = float('inf')
-        diff = rmse
         sweeps = 0
         self.rmse_history_ = []
-        while (diff > self.tol) if self.max_iter is None else (sweeps < self.max_iter):
-            engine.half_sweep_users()
-            engine.half_sweep_items()
-            new_rmse = engine.train_rmse()
-            diff = rmse - new_rmse
-            rmse = new_rmse
-            sweeps += 1
+        nnz = engine.nnz
+
+        def to_rmse(sse):
+            return float(np.sqrt(float(sse.cpu()[0]) / nnz)) if nnz else float('nan')
+
+        def record(new_rmse):
             self.rmse_history_.append(new_rmse)
             if self.verbose:
                 print('sweep %d: train rmse %.6f' % (sweeps, new_rmse))
-            if not np.isfinite(new_rmse):
+
+        by_tol = self.max_iter is None
+        go = by_tol or self.max_iter > 0  # the reference always runs the first sweep
+        if go:
+            engine.half_sweep_users()
+            engine.half_sweep_items()
+            sweeps = 1
+        pending = go
+        while pending:
+            if not by_tol and sweeps >= self.max_iter:
                 break
+            new_rmse = to_rmse(engine.half_sweep_users_err(keep_old=by_tol))
+            record(new_rmse)
+            diff = rmse - new_rmse
+            rmse = new_rmse
+            if (by_tol and not diff > self.tol) or not np.isfinite(new_rmse):
+                if by_tol:
+                    engine.discard_users()
+                pending = False
+                break
+            if by_tol:
+                engine.commit_users()
+            engine.half_sweep_items()
+            sweeps += 1
+        if pending:  # the last sweep's error was not needed to decide anything
+            record(engine.train_rmse())
         self.n_iter_ = sweeps
         self.user_feats, self.item_feats = engine.get_factors()
         self.reconstruction_err_ = self.score(X, y)

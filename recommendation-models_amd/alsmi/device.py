@@ -141,6 +141,23 @@ class SweepPlan(object):
             self._handle, _ptr(s.indptr), _ptr(s.indices), _ptr(s.vals), _ptr(src),
             max(int(src.shape[0]), 1), _ptr(dst), float(alpha), _stream()), 'alsmi_half_sweep')
 
+    def half_sweep_err(self, src, cur, dst, alpha):
+        """half_sweep that also returns the squared training error of the vectors it
+        replaces: sum over the plan's stored entries of (val - <cur[r], src[col]>)^2, a
+        1-element fp64 device tensor (src/als.py:161-165, fused).  cur may be dst."""
+        self._check_tables(src, dst)
+        self._check_tables(src, cur)
+        s = self.side
+        sse = torch.zeros(1, dtype=torch.float64, device=s.device)
+        if s.nnz == 0:
+            dst[self.row_begin:self.row_end].zero_()
+            return sse
+        _lib.check(_lib.load().alsmi_half_sweep_err(
+            self._handle, _ptr(s.indptr), _ptr(s.indices), _ptr(s.vals), _ptr(src),
+            max(int(src.shape[0]), 1), _ptr(cur), _ptr(dst), float(alpha), _ptr(sse), _stream()),
+            'alsmi_half_sweep_err')
+        return sse
+
     def normal_equations(self, src, alpha):
         """Test aid: (A [rows x ld x ld], b [rows x ld]) before the solve."""
         self._check_tables(src, None)

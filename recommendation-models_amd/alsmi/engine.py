@@ -91,7 +91,8 @@ class AlsEngine(object):
         self.kp = b.padded_rank(self.rank)
         self.U = b.zeros(self.n, self.kp, self.dtype)
         self.V = b.zeros(self.m, self.kp, self.dtype)
-        self.pair_rows = self.csr.expand_rows()  # local row ids of this rank's entries
+        self._U_next, self._pending = None, False
+        self._pair_rows = None
         self.local_nnz = self.csr.nnz
         if total_nnz is None:
             total_nnz = self.local_nnz
@@ -169,6 +170,40 @@ class AlsEngine(object):
         self.plan_u.half_sweep(self.V, self.U[self.ulo:self.uhi], self.alpha)
         self._all_gather_rows(self.U, self.user_bounds)
 
+    def half_sweep_users_err(self, keep_old=False):
+        """The user half-sweep, which also gives the squared training error of the
+        factors as they are BEFORE it (the error the reference computes at the end of the
+        previous sweep, src/als.py:161-165) at no extra pass over the ratings.  Returns the
+        all-reduced 1-element fp64 device tensor.  With keep_old the new rows are parked
+        in a side table until ``commit_users()`` (or dropped by ``discard_users()``), so
+        a caller that decides to stop on that error still holds the factors it belongs to."""
+        mine = self.U[self.ulo:self.uhi]
+        if keep_old:
+            if self._U_next is None:
+                self._U_next = torch.zeros_like(mine)
+            dst = self._U_next
+        else:
+            dst = mine
+        sse = self.plan_u.half_sweep_err(self.V, mine, dst, self.alpha)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(sse, group=self.group)
+        if keep_old:
+            self._pending = True
+        else:
+            self._all_gather_rows(self.U, self.user_bounds)
+        return sse
+
+    def commit_users(self):
+        if not self._pending:
+            raise RuntimeError('no parked user half-sweep to commit')
+        self.U[self.ulo:self.uhi].copy_(self._U_next)
+        self._pending = False
+        self._all_gather_rows(self.U, self.user_bounds)
+
+    def discard_users(self):
+        self._pending = False
+
     def half_sweep_items(self):
         self.plan_i.half_sweep(self.U, self.V[self.ilo:self.ihi], self.alpha)
         self._all_gather_rows(self.V, self.item_bounds)
@@ -176,7 +211,9 @@ class AlsEngine(object):
     def train_sse_async(self):
         """Sum of squared errors over all stored entries as a 1-element fp64 device
         tensor (src/als.py:161-165 before the mean and sqrt)."""
-        _, sse = self.backend.sddmm(self.rank, self.pair_rows, self.csr.indices,
+        if self._pair_rows is None:  # local row id of every stored entry, built on first use
+            self._pair_rows = self.csr.expand_rows()
+        _, sse = self.backend.sddmm(self.rank, self._pair_rows, self.csr.indices,
                                     self.U[self.ulo:self.uhi], self.V, self.csr.vals, False)
         if self.world > 1:
             import torch.distributed as dist

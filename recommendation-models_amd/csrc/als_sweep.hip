@@ -37,7 +37,7 @@ __host__ __device__ constexpr int tri_index(int e, int f, int nv) {
 template <typename T, int NV>
 struct Gram {
     static constexpr int NTRI = NV * (NV + 1) / 2;
-    static constexpr int SLAB_SLOTS = NTRI * 4 + NV;  // x 64 lanes
+    static constexpr int SLAB_SLOTS = NTRI * 4 + NV + 1;  // x 64 lanes; last = error partial
     typename Mfma<T>::acc_t acc[NTRI];
     T b[NV];
 
@@ -47,7 +47,7 @@ struct Gram {
 #pragma unroll
         for (int e = 0; e < NV; ++e) b[e] = T(0);
     }
-    __device__ __forceinline__ void store(T *slab, int lane) const {
+    __device__ __forceinline__ void store(T *slab, int lane, T err) const {
         int s = 0;
 #pragma unroll
         for (int t = 0; t < NTRI; ++t)
@@ -55,8 +55,9 @@ struct Gram {
             for (int r = 0; r < 4; ++r) slab[(s++) * WAVE + lane] = acc[t][r];
 #pragma unroll
         for (int e = 0; e < NV; ++e) slab[(s++) * WAVE + lane] = b[e];
+        slab[s * WAVE + lane] = err;
     }
-    __device__ __forceinline__ void add(const T *slab, int lane) {
+    __device__ __forceinline__ void add(const T *slab, int lane, T &err) {
         int s = 0;
 #pragma unroll
         for (int t = 0; t < NTRI; ++t)
@@ -64,8 +65,53 @@ struct Gram {
             for (int r = 0; r < 4; ++r) acc[t][r] += slab[(s++) * WAVE + lane];
 #pragma unroll
         for (int e = 0; e < NV; ++e) b[e] += slab[(s++) * WAVE + lane];
+        err += slab[s * WAVE + lane];
     }
 };
+
+// Squared error of a row's CURRENT vector u against its stored entries, from the normal
+// equations the half-sweep builds anyway (src/als.py:161-165 computes the same quantity in a
+// separate pass over all entries):
+//     sum_t (r_t - <u, f_t>)^2 = sum_t r_t^2 - 2 <u, b> + u^T G u,   G = sum f f^T, b = sum r f.
+// Only sum r^2 has to be collected per entry (ErrAcc; ON = false compiles to nothing); the
+// two products are taken once per row from the accumulators (row_error_part).  Every rating is
+// seen by the 16 lanes of a group, so the per-lane sums count it 16 times; row_error_part
+// divides.
+template <typename T, int NV, bool ON>
+struct ErrAcc {
+    T sum;
+    __device__ __forceinline__ void init() { sum = T(0); }
+    __device__ __forceinline__ void add(T rating) {
+        if constexpr (ON) sum += rating * rating;
+    }
+};
+
+// This lane's share of the row's squared error; the shares of the 64 lanes add up to it.
+// Must run before the ridge goes into the accumulators.  cur_row = the row's current vector
+// (KP elements).  Tile (e,f), register r of lane (g,q) holds G[crow(g,r)*NV+e][q*NV+f]; an
+// off-diagonal tile stands for its mirror image too.
+template <typename T, int NV>
+__device__ __forceinline__ double row_error_part(const Gram<T, NV> &G, T r2,
+                                                 const T *__restrict__ cur_row, int lane) {
+    const int g = lane >> 4, q = lane & 15;
+    T uc[NV], ur[4][NV];
+    load_vec<T, NV>(uc, cur_row + q * NV);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) load_vec<T, NV>(ur[r], cur_row + Mfma<T>::crow(g, r) * NV);
+    T ub = T(0), quad = T(0);
+#pragma unroll
+    for (int e = 0; e < NV; ++e) ub += G.b[e] * uc[e];
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = e; f < NV; ++f) {
+            T t = T(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t += G.acc[tri_index(e, f, NV)][r] * ur[r][e];
+            quad += (e == f ? T(1) : T(2)) * t * uc[f];
+        }
+    return (double)r2 * 0.0625 - 2.0 * (double)ub + (double)quad;
+}
 
 // One k=4 MFMA step: four neighbours (one per lane group), all upper tiles.
 template <typename T, int NV>
@@ -80,9 +126,10 @@ __device__ __forceinline__ void gram_step(Gram<T, NV> &G, const T (&v)[NV], T rv
 }
 
 // U consecutive k=4 steps starting at step s: issue all their gathers first, then the MFMAs.
-template <typename T, int NV, int U>
-__device__ __forceinline__ void gram_steps(Gram<T, NV> &G, const T *__restrict__ srcq, int idx,
-                                           T rv, int s, int g) {
+template <typename T, int NV, int U, bool ERR>
+__device__ __forceinline__ void gram_steps(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E,
+                                           const T *__restrict__ srcq, int idx, T rv, int s,
+                                           int g) {
     constexpr int KP = NV * 16;
     T v[U][NV];
     T r[U];
@@ -94,13 +141,17 @@ __device__ __forceinline__ void gram_steps(Gram<T, NV> &G, const T *__restrict__
         load_vec<T, NV>(v[u], srcq + (int64_t)id * KP);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) gram_step<T, NV>(G, v[u], r[u]);
+    for (int u = 0; u < U; ++u) {
+        E.add(r[u]);
+        gram_step<T, NV>(G, v[u], r[u]);
+    }
 }
 
 // Accumulate entries [beg, end) of one row.  The index / rating block of the next 64 entries
 // is requested before the current block is processed.
-template <typename T, int NV>
-__device__ __forceinline__ void gram_range(Gram<T, NV> &G, const int32_t *__restrict__ indices,
+template <typename T, int NV, bool ERR>
+__device__ __forceinline__ void gram_range(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E,
+                                           const int32_t *__restrict__ indices,
                                            const T *__restrict__ vals,
                                            const T *__restrict__ src, int64_t beg, int64_t end,
                                            int lane) {
@@ -128,14 +179,15 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, const int32_t *__rest
         }
         const int nfull = cnt >> 2;
         int s = 0;
-        for (; s + DEEP <= nfull; s += DEEP) gram_steps<T, NV, DEEP>(G, srcq, idx, rv, s, g);
+        for (; s + DEEP <= nfull; s += DEEP)
+            gram_steps<T, NV, DEEP, ERR>(G, E, srcq, idx, rv, s, g);
         if constexpr (DEEP > 4) {
             if (s + 4 <= nfull) {
-                gram_steps<T, NV, 4>(G, srcq, idx, rv, s, g);
+                gram_steps<T, NV, 4, ERR>(G, E, srcq, idx, rv, s, g);
                 s += 4;
             }
         }
-        for (; s < nfull; ++s) gram_steps<T, NV, 1>(G, srcq, idx, rv, s, g);
+        for (; s < nfull; ++s) gram_steps<T, NV, 1, ERR>(G, E, srcq, idx, rv, s, g);
         if (cnt & 3) {  // last, partial step: lanes past the end contribute zeros
             const int sl = 4 * nfull + g;
             const int id = __shfl(idx, sl);
@@ -145,6 +197,7 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, const int32_t *__rest
             const bool valid = sl < cnt;
 #pragma unroll
             for (int e = 0; e < NV; ++e) v[e] = valid ? v[e] : T(0);
+            E.add(r1);
             gram_step<T, NV>(G, v, r1);
         }
     }
@@ -170,8 +223,8 @@ __device__ __forceinline__ unsigned hi16_pair(unsigned lo_elem, unsigned hi_elem
 
 // 32 neighbours, at entries off .. off+31 of the wave's 64-entry index block; `valid` of them
 // exist (FULL: all 32).
-template <int NV, bool FULL>
-__device__ __forceinline__ void gram_block32_split(Gram<float, NV> &G,
+template <int NV, bool FULL, bool ERR>
+__device__ __forceinline__ void gram_block32_split(Gram<float, NV> &G, ErrAcc<float, NV, ERR> &E,
                                                    const float *__restrict__ srcq, int idx,
                                                    float rv, int off, int valid, int g) {
     constexpr int KP = NV * 16;
@@ -190,9 +243,11 @@ __device__ __forceinline__ void gram_block32_split(Gram<float, NV> &G,
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 8; ++j) {
+        E.add(r[j]);
 #pragma unroll
         for (int e = 0; e < NV; ++e) G.b[e] += r[j] * v[j][e];
+    }
     bf16x8 H[NV], M[NV], L[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
@@ -236,8 +291,8 @@ __device__ __forceinline__ void gram_block32_split(Gram<float, NV> &G,
 }
 
 // Accumulate entries [beg, end) of one row on the bf16 matrix cores (fp32 data).
-template <int NV>
-__device__ __forceinline__ void gram_range_split(Gram<float, NV> &G,
+template <int NV, bool ERR>
+__device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<float, NV, ERR> &E,
                                                  const int32_t *__restrict__ indices,
                                                  const float *__restrict__ vals,
                                                  const float *__restrict__ src, int64_t beg,
@@ -262,13 +317,13 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G,
             rv_n = vals[base + WAVE + lane];
         }
         if (cnt >= 32)
-            gram_block32_split<NV, true>(G, srcq, idx, rv, 0, 32, g);
+            gram_block32_split<NV, true, ERR>(G, E, srcq, idx, rv, 0, 32, g);
         else
-            gram_block32_split<NV, false>(G, srcq, idx, rv, 0, cnt, g);
+            gram_block32_split<NV, false, ERR>(G, E, srcq, idx, rv, 0, cnt, g);
         if (cnt == 64)
-            gram_block32_split<NV, true>(G, srcq, idx, rv, 32, 32, g);
+            gram_block32_split<NV, true, ERR>(G, E, srcq, idx, rv, 32, 32, g);
         else if (cnt > 32)
-            gram_block32_split<NV, false>(G, srcq, idx, rv, 32, cnt - 32, g);
+            gram_block32_split<NV, false, ERR>(G, E, srcq, idx, rv, 32, cnt - 32, g);
     }
 }
 
@@ -281,19 +336,21 @@ constexpr bool use_split() {
     return sizeof(T) == 4 && NV <= 4 && !FP32_MFMA;
 }
 
-template <typename T, int NV, bool SPLIT>
-__device__ __forceinline__ void gram_accumulate(Gram<T, NV> &G, const int32_t *indices,
-                                                const T *vals, const T *src, int64_t beg,
-                                                int64_t end, int lane) {
+template <typename T, int NV, bool SPLIT, bool ERR>
+__device__ __forceinline__ void gram_accumulate(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E,
+                                                const int32_t *indices, const T *vals,
+                                                const T *src, int64_t beg, int64_t end,
+                                                int lane) {
     if constexpr (SPLIT && sizeof(T) == 4)
-        gram_range_split<NV>(G, indices, vals, src, beg, end, lane);
+        gram_range_split<NV, ERR>(G, E, indices, vals, src, beg, end, lane);
     else
-        gram_range<T, NV>(G, indices, vals, src, beg, end, lane);
+        gram_range<T, NV, ERR>(G, E, indices, vals, src, beg, end, lane);
 }
 
 // ---- kernel 1: partial normal equations of the chunks of long rows ---------------------
-template <typename T, int NV, bool FP32_MFMA = false>
-__global__ __launch_bounds__(256) void gram_chunks_kernel(
+// ERR: also the chunk's sum of squared ratings (last slab slot).
+template <typename T, int NV, bool FP32_MFMA = false, bool ERR = false>
+__global__ __launch_bounds__(256, (NV == 4 ? 2 : 1)) void gram_chunks_kernel(
     const int64_t *__restrict__ ch_beg, const int64_t *__restrict__ ch_end, int n_chunks,
     const int32_t *__restrict__ indices, const T *__restrict__ vals, const T *__restrict__ src,
     T *__restrict__ slabs) {
@@ -302,9 +359,26 @@ __global__ __launch_bounds__(256) void gram_chunks_kernel(
     if (w >= n_chunks) return;
     Gram<T, NV> G;
     G.zero();
-    gram_accumulate<T, NV, use_split<T, NV, FP32_MFMA>()>(G, indices, vals, src, ch_beg[w],
-                                                          ch_end[w], lane);
-    G.store(slabs + (size_t)w * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
+    ErrAcc<T, NV, ERR> E;
+    E.init();
+    gram_accumulate<T, NV, use_split<T, NV, FP32_MFMA>(), ERR>(G, E, indices, vals, src,
+                                                               ch_beg[w], ch_end[w], lane);
+    G.store(slabs + (size_t)w * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane, E.sum);
+}
+
+// Sum of the per-wave squared-error partials, in index order, by one thread block.
+__global__ __launch_bounds__(256) void sum_err_kernel(const double *__restrict__ part, int n,
+                                                      double *__restrict__ out) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 // ---- kernel 1b: add the slabs of each long row into its first slab -----------------------
@@ -575,85 +649,6 @@ __device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int l
     return bad == 0;
 }
 
-// One elimination step of the in-register LDL^T, P known at compile time so that every
-// register index is static (a runtime-indexed row would be demoted to scratch memory).
-template <typename T, int KP, int P>
-struct LdlStep {
-    static __device__ __forceinline__ void run(T (&a)[KP], T &bb, T &w, int &bad, int lane) {
-        constexpr int BATCH = 8;
-        const T u = a[P];  // column P of the current Schur complement, one element per lane
-        const T d = read_lane(u, P);
-        bad |= (d > T(0)) ? 0 : 1;
-        const T inv = pivot_rcp(d);
-        const T zp = read_lane(bb, P);
-        const T l = u * inv;  // L[row][P]
-        a[P] = l;
-        w = (lane == P) ? zp * inv : w;
-        bb -= l * zp;
-#pragma unroll
-        for (int c0 = P + 1; c0 < KP; c0 += BATCH) {
-            T sc[BATCH];
-#pragma unroll
-            for (int i = 0; i < BATCH; ++i)
-                if (c0 + i < KP) sc[i] = read_lane(u, c0 + i);  // A[c][P]
-#pragma unroll
-            for (int i = 0; i < BATCH; ++i)
-                if (c0 + i < KP) a[c0 + i] -= l * sc[i];
-        }
-        LdlStep<T, KP, P + 1>::run(a, bb, w, bad, lane);
-    }
-};
-template <typename T, int KP>
-struct LdlStep<T, KP, KP> {
-    static __device__ __forceinline__ void run(T (&)[KP], T &, T &, int &, int) {}
-};
-
-// LDL^T factorisation + solve with one matrix row per lane held in registers (KP <= 64).
-// A = L D L^T with unit lower-triangular L needs no square roots; the forward substitution
-// is fused into the factorisation.  Returns false when a pivot is not positive (the matrix
-// is not positive definite).
-template <typename T, int KP>
-__device__ __forceinline__ bool ldl_solve_regs(T *Asm, const T *bsm, int lane, T &x_out) {
-    constexpr int LD = Slab<T, KP>::LD;
-    constexpr int VW = 16 / (int)sizeof(T);
-    typedef T vec_t __attribute__((ext_vector_type(VW)));
-    const int row = lane < KP ? lane : KP - 1;
-    T a[KP];
-#pragma unroll
-    for (int c = 0; c < KP; c += VW) {
-        const vec_t t = *reinterpret_cast<const vec_t *>(Asm + row * LD + c);
-#pragma unroll
-        for (int i = 0; i < VW; ++i) a[c + i] = t[i];
-    }
-    T bb = bsm[row];
-    T w = T(0);   // lane p ends with z_p / d_p
-    int bad = 0;  // bitwise, so that no step is skipped through an early-out branch
-    LdlStep<T, KP, 0>::run(a, bb, w, bad, lane);
-    // L back to LDS, row-major, for the transposed reads of the back substitution
-    if (lane < KP) {
-#pragma unroll
-        for (int c = 0; c < KP; c += VW) {
-            vec_t t;
-#pragma unroll
-            for (int i = 0; i < VW; ++i) t[i] = a[c + i];
-            *reinterpret_cast<vec_t *>(Asm + row * LD + c) = t;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // L^T x = w, column oriented: lane j keeps w_j - sum_{c>p} L[c][j] x_c
-    T x = T(0);
-#pragma unroll 8
-    for (int p = KP - 1; p >= 0; --p) {
-        const T xp = read_lane(w, p);
-        x = (lane == p) ? xp : x;
-        const T l = Asm[p * LD + row];  // L[p][row]
-        w -= l * xp;
-    }
-    x_out = x;
-    return bad == 0;
-}
-
 // Generic in-LDS Cholesky + solve for any KP (two rows per lane at KP = 128).  Works on the
 // upper triangle stored row-major so that every vector access is contiguous over lanes.
 template <typename T, int KP>
@@ -734,6 +729,9 @@ struct SolveArgs {
     T *A_out;
     T *b_out;
     int64_t row_begin;
+    // squared error of the rows' current vectors (ERR builds only)
+    const T *cur;      // table the rows' current vectors are read from (may be dst)
+    double *err_part;  // [waves of the grid]
 };
 
 // LDS elements one wave needs: the small transposition stage on the fast path (padded rank
@@ -751,8 +749,11 @@ struct WaveLds {
 // instead of four broadcast reads in flight per elimination step (more registers, one wave
 // per SIMD fewer), 4 = Gram build on the fp32 MFMA instead of the bf16 matrix cores (both kernels).  The
 // production kernel is the ABLATE = 0 instantiation and contains none of that code.
-template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0>
-__global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
+// ERR builds also sum (rating - <current vector, neighbour>)^2 over every entry they read: the
+// training error of the factors BEFORE this half-sweep, at no extra memory traffic.
+template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0, bool ERR = false>
+__global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_rows_kernel(
+    SolveArgs<T> p) {
     constexpr int KP = NV * 16;
     constexpr int LD = Slab<T, KP>::LD;
     constexpr int R = (KP + 63) / 64;
@@ -764,6 +765,7 @@ __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
     T *bsm = Asm + KP * (FAST ? Stage<T, KP < 64 ? KP : 64>::LD : LD);
     T *dsm = bsm + KP;
     const int W = gridDim.x * WPB;
+    double lane_err = 0.0;  // this lane's share of the squared error of the wave's rows
     for (int t = blockIdx.x * WPB + wl; t < p.n_tasks; t += W) {
         const int row = p.order[t];
         const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
@@ -783,13 +785,17 @@ __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
         Gram<T, NV> G;
         G.zero();
         const int sf = p.slab_first[t];
+        ErrAcc<T, NV, ERR> E;
+        E.init();
         if (sf >= 0) {
             // a long row: sum_slabs_kernel left the sum of its chunks in its first slab
-            G.add(p.slabs + (size_t)sf * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane);
+            G.add(p.slabs + (size_t)sf * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane, E.sum);
         } else if constexpr (ABLATE != 2) {
-            gram_accumulate<T, NV, use_split<T, NV, ABLATE == 4>()>(G, p.indices, p.vals, p.src,
-                                                                    beg, end, lane);
+            gram_accumulate<T, NV, use_split<T, NV, ABLATE == 4>(), ERR>(
+                G, E, p.indices, p.vals, p.src, beg, end, lane);
         }
+        if constexpr (ERR)
+            lane_err += row_error_part<T, NV>(G, E.sum, p.cur + (int64_t)row * KP, lane);
         if constexpr (ABLATE == 1) {
             T sum = G.b[0];
 #pragma unroll
@@ -810,10 +816,6 @@ __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
             T *Ao = p.A_out + (row - p.row_begin) * (int64_t)KP * KP;
             for (int i = lane; i < KP * KP; i += WAVE) Ao[i] = Asm[(i / KP) * LD + (i % KP)];
             for (int i = lane; i < KP; i += WAVE) p.b_out[(row - p.row_begin) * KP + i] = bsm[i];
-        } else if constexpr (KP <= 64) {
-            T x;
-            const bool ok = ldl_solve_regs<T, KP>(Asm, bsm, lane, x);
-            if (lane < KP) out[lane] = ok ? x : T(0);
         } else {
             T x[R];
             const bool ok = chol_solve_lds<T, KP>(Asm, bsm, dsm, lane, x);
@@ -823,6 +825,10 @@ __global__ __launch_bounds__(WPB * 64) void solve_rows_kernel(SolveArgs<T> p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (ERR) {
+        const double wave_err = wave_sum(lane_err);
+        if (lane == 0) p.err_part[blockIdx.x * WPB + wl] = wave_err;
     }
 }
 
@@ -838,27 +844,33 @@ struct alsmi_plan {
     int64_t *ch_beg, *ch_end;
     void *slabs;
     size_t slab_bytes;
+    double *err_part;  // one squared-error partial per wave of the solve grid
+    int err_part_cap;
 };
 
 namespace alsmi {
 
 static size_t slab_slots(int kp) {
     const int nv = kp / 16;
-    return (size_t)(nv * (nv + 1) / 2 * 4 + nv) * WAVE;
+    return (size_t)(nv * (nv + 1) / 2 * 4 + nv + 1) * WAVE;
 }
 
 template <typename T, int NV, int WPB>
-static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, hipStream_t st) {
+static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, double *err_out,
+                        hipStream_t st) {
     constexpr int KP = NV * 16;
     const size_t lds =
         (dump ? WaveLds<T, KP, true>::BYTES : WaveLds<T, KP, false>::BYTES) * WPB;
     auto kern = dump ? solve_rows_kernel<T, NV, WPB, true> : solve_rows_kernel<T, NV, WPB, false>;
+    if (err_out) kern = solve_rows_kernel<T, NV, WPB, false, 0, true>;
     if constexpr (sizeof(T) == 4 && NV == 4) {
+        if (!err_out) {
         static const int ablate = getenv("ALSMI_ABLATE") ? atoi(getenv("ALSMI_ABLATE")) : 0;
         if (!dump && ablate == 1) kern = solve_rows_kernel<T, NV, WPB, false, 1>;
         if (!dump && ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
         if (!dump && ablate == 3) kern = solve_rows_kernel<T, NV, WPB, false, 3>;
         if (!dump && ablate == 4) kern = solve_rows_kernel<T, NV, WPB, false, 4>;
+        }
     }
     ALSMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -873,22 +885,29 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, hipStre
     int grid = pl->cu_count * bpc;
     const int need = (pl->n_tasks + WPB - 1) / WPB;
     if (grid > need) grid = need;
+    if (err_out && grid * WPB > pl->err_part_cap) grid = pl->err_part_cap / WPB;
     if (grid < 1) return ALSMI_OK;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), lds, st, a);
     ALSMI_HIP_CHECK(hipGetLastError());
+    if (err_out) {
+        hipLaunchKernelGGL(sum_err_kernel, dim3(1), dim3(256), 0, st, pl->err_part, grid * WPB,
+                           err_out);
+        ALSMI_HIP_CHECK(hipGetLastError());
+    }
     return ALSMI_OK;
 }
 
 template <typename T, int NV, int WPB>
 static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
                           const void *vals, const void *src, void *dst, double alpha, void *A_out,
-                          void *b_out, hipStream_t st) {
+                          void *b_out, const void *cur, double *err_out, hipStream_t st) {
     if (pl->n_chunks > 0) {
         const int grid = (pl->n_chunks + 3) / 4;
         auto chunks = gram_chunks_kernel<T, NV, false>;
+        if (err_out) chunks = gram_chunks_kernel<T, NV, false, true>;
         if constexpr (sizeof(T) == 4 && NV == 4) {
             static const int ablate = getenv("ALSMI_ABLATE") ? atoi(getenv("ALSMI_ABLATE")) : 0;
-            if (ablate == 4) chunks = gram_chunks_kernel<T, NV, true>;
+            if (ablate == 4 && !err_out) chunks = gram_chunks_kernel<T, NV, true>;
         }
         hipLaunchKernelGGL(chunks, dim3(grid), dim3(256), 0, st, pl->ch_beg, pl->ch_end,
                            pl->n_chunks, indices, static_cast<const T *>(vals),
@@ -917,14 +936,17 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     a.A_out = static_cast<T *>(A_out);
     a.b_out = static_cast<T *>(b_out);
     a.row_begin = pl->row_begin;
-    return launch_solve<T, NV, WPB>(pl, a, A_out != nullptr, st);
+    a.cur = static_cast<const T *>(cur);
+    a.err_part = pl->err_part;
+    return launch_solve<T, NV, WPB>(pl, a, A_out != nullptr, err_out, st);
 }
 
 static int dispatch(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
                     const void *vals, const void *src, void *dst, double alpha, void *A_out,
-                    void *b_out, hipStream_t st) {
-#define ALSMI_CASE(T, NV, WPB) \
-    return run_half_sweep<T, NV, WPB>(pl, indptr, indices, vals, src, dst, alpha, A_out, b_out, st)
+                    void *b_out, const void *cur, double *err_out, hipStream_t st) {
+#define ALSMI_CASE(T, NV, WPB)                                                                  \
+    return run_half_sweep<T, NV, WPB>(pl, indptr, indices, vals, src, dst, alpha, A_out, b_out, \
+                                      cur, err_out, st)
     if (pl->dtype == ALSMI_F32) {
         switch (pl->kp) {
             case 16: ALSMI_CASE(float, 1, 4);
@@ -1025,6 +1047,9 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     if (e == hipSuccess) e = upload((void **)&pl->ch_beg, ch_beg.data(), ch_beg.size() * 8);
     if (e == hipSuccess) e = upload((void **)&pl->ch_end, ch_end.data(), ch_end.size() * 8);
     if (e == hipSuccess) e = upload(&pl->slabs, nullptr, pl->slab_bytes);
+    pl->err_part_cap = pl->cu_count * 64;
+    if (e == hipSuccess)
+        e = upload((void **)&pl->err_part, nullptr, (size_t)pl->err_part_cap * sizeof(double));
     if (e != hipSuccess) {
         set_error("alsmi_plan_create: device allocation failed: %s", hipGetErrorString(e));
         alsmi_plan_destroy(pl);
@@ -1042,6 +1067,7 @@ int alsmi_plan_destroy(alsmi_plan *pl) {
     (void)hipFree(pl->ch_beg);
     (void)hipFree(pl->ch_end);
     (void)hipFree(pl->slabs);
+    (void)hipFree(pl->err_part);
     delete pl;
     return ALSMI_OK;
 }
@@ -1074,7 +1100,24 @@ int alsmi_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *indic
     if (pl->n_tasks == 0) return ALSMI_OK;
     ALSMI_REQUIRE(dst_factors, "alsmi_half_sweep: null destination");
     return alsmi::dispatch(pl, indptr, indices, vals, src_factors, dst_factors, alpha, nullptr,
-                           nullptr, static_cast<hipStream_t>(stream));
+                           nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int alsmi_half_sweep_err(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
+                         const void *vals, const void *src_factors, int64_t n_src,
+                         const void *cur_factors, void *dst_factors, double alpha,
+                         double *sse_out, void *stream) {
+    int rc =
+        check_sweep_args(pl, indptr, indices, vals, src_factors, n_src, "alsmi_half_sweep_err");
+    if (rc != ALSMI_OK) return rc;
+    ALSMI_REQUIRE(sse_out, "alsmi_half_sweep_err: null sse_out");
+    if (pl->n_tasks == 0) {
+        ALSMI_HIP_CHECK(hipMemsetAsync(sse_out, 0, sizeof(double), static_cast<hipStream_t>(stream)));
+        return ALSMI_OK;
+    }
+    ALSMI_REQUIRE(dst_factors && cur_factors, "alsmi_half_sweep_err: null factor table");
+    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, dst_factors, alpha, nullptr,
+                           nullptr, cur_factors, sse_out, static_cast<hipStream_t>(stream));
 }
 
 int alsmi_normal_equations(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
@@ -1086,7 +1129,7 @@ int alsmi_normal_equations(alsmi_plan *pl, const int64_t *indptr, const int32_t 
     if (pl->n_tasks == 0) return ALSMI_OK;
     ALSMI_REQUIRE(A_out && b_out, "alsmi_normal_equations: null output");
     return alsmi::dispatch(pl, indptr, indices, vals, src_factors, nullptr, alpha, A_out, b_out,
-                           static_cast<hipStream_t>(stream));
+                           nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

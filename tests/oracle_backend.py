@@ -39,6 +39,19 @@ class OraclePlan(object):
         dst[:s.n_rows, :self.rank] = torch.from_numpy(out)
 
 
+    def half_sweep_err(self, src, cur, dst, alpha):
+        s = self.side
+        sse = torch.zeros(1, dtype=torch.float64)
+        if s.n_rows == 0:
+            return sse
+        rows = np.repeat(np.arange(s.n_rows), np.diff(s.indptr_host))
+        pred = (cur[:s.n_rows, :self.rank].numpy()[rows] *
+                src[:, :self.rank].numpy()[s.indices_np]).sum(-1)
+        sse[0] = float(((s.vals_np - pred) ** 2).sum())
+        self.half_sweep(src, dst, alpha)
+        return sse
+
+
 class OracleBackend(object):
     def make_side(self, indptr, indices, vals, n_rows, n_cols, dtype):
         return OracleSide(indptr, indices, vals, n_rows, n_cols, dtype)

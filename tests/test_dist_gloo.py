@@ -53,10 +53,24 @@ def worker(rank_id, world, port, case, out_dir):
         assert eng.nnz == int(P['indptr'][-1])
         eng.set_factors(np.zeros_like(P['U']), P['V'])
         hist = []
-        for _ in range(2):
-            eng.half_sweep_users()
-            eng.half_sweep_items()
-            hist.append(float(eng.train_sse_async()[0]))
+        eng.half_sweep_users()
+        eng.half_sweep_items()
+        hist.append(float(eng.train_sse_async()[0]))
+        # second sweep on the fused schedule: its user half reports the error of sweep 1
+        # and parks the new rows until they are committed
+        before = eng.U.clone()
+        fused = float(eng.half_sweep_users_err(keep_old=True)[0])
+        assert abs(fused - hist[0]) <= 1e-10 * abs(hist[0])
+        assert torch.equal(eng.U, before)
+        eng.commit_users()
+        eng.half_sweep_items()
+        hist.append(float(eng.train_sse_async()[0]))
+        # a parked half-sweep that is dropped leaves the factors alone
+        before = eng.U.clone()
+        again = float(eng.half_sweep_users_err(keep_old=True)[0])
+        eng.discard_users()
+        assert abs(again - hist[1]) <= 1e-10 * abs(hist[1])
+        assert torch.equal(eng.U, before)
         uf, itf = eng.get_factors()
         np.savez(os.path.join(out_dir, 'rank%d.npz' % rank_id), uf=uf, itf=itf, hist=hist,
                  ub=eng.user_bounds, ib=eng.item_bounds)

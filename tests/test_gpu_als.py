@@ -81,6 +81,50 @@ def test_normal_equations_and_half_sweep(gpu, case, dtype):
     plan.close()
 
 
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'k%d' % c[4])
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_half_sweep_with_error_of_replaced_factors(gpu, case, dtype):
+    """alsmi_half_sweep_err: same new vectors as alsmi_half_sweep, plus the squared
+    training error of the vectors it replaces (src/als.py:161-165), for short rows, rows cut
+    into chunks and empty rows, out of place and in place."""
+    device, torch = gpu
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    seed, n, m, nnz, rank, chunk, extra = case
+    P = random_problem(seed, n, m, nnz, rank, **extra)
+    alpha = 0.1
+    side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], n, m, dtype, device)
+    plan = dev.SweepPlan(side, rank, chunk=chunk)
+    V = dev.factors_to_device(P['V'], dtype, device)
+    Ucur = dev.factors_to_device(P['U'], dtype, device)
+    kp = dev.padded_rank(rank)
+    plain = torch.full((n, kp), 7.0, dtype=V.dtype, device=device)
+    plan.half_sweep(V, plain, alpha)
+    want_sse = ao.train_sse(P['indptr'], P['indices'], P['vals'],
+                            dev.factors_to_host(Ucur, rank), dev.factors_to_host(V, rank))
+    # the error comes from sum r^2 - 2 u.b + u^T G u, whose terms cancel: 2e-5 on the sum of
+    # squares is the 1e-5 bar on the RMSE
+    tol = 1e-12 if dtype == 'float64' else 2e-5
+    out = torch.full((n, kp), 7.0, dtype=V.dtype, device=device)
+    keep = Ucur.clone()
+    sse = plan.half_sweep_err(V, Ucur, out, alpha)
+    assert torch.equal(Ucur, keep)
+    # same arithmetic as the plain entry point, but a separately compiled kernel
+    assert col_rel_err(dev.factors_to_host(out, rank), dev.factors_to_host(plain, rank)) < \
+        (1e-12 if dtype == 'float64' else 1e-5)
+    assert not out[:, rank:].any()
+    assert abs(float(sse.cpu()[0]) - want_sse) <= tol * want_sse
+    # in place, twice: the second call sees the new vectors
+    sse2 = plan.half_sweep_err(V, Ucur, Ucur, alpha)
+    assert torch.equal(Ucur, out)
+    assert float(sse2.cpu()[0]) == float(sse.cpu()[0])
+    sse3 = plan.half_sweep_err(V, Ucur, Ucur, alpha)
+    want3 = ao.train_sse(P['indptr'], P['indices'], P['vals'],
+                         dev.factors_to_host(out, rank), dev.factors_to_host(V, rank))
+    assert abs(float(sse3.cpu()[0]) - want3) <= tol * max(want3, 1e-30)
+    plan.close()
+
+
 def test_half_sweep_singular_gives_zeros(gpu):
     """A = 0 (zero source factors, alpha = 0): the reference's inv() raises
     LinAlgError and the row becomes zeros (src/als.py:246-249)."""

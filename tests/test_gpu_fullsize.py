@@ -93,6 +93,17 @@ def test_whole_matrix_properties_fp32(problem):
         eng.sweep()
         rmse.append(eng.train_rmse())
     assert all(np.isfinite(rmse)) and all(b <= a * (1 + 1e-6) for a, b in zip(rmse, rmse[1:]))
+    # the error a user half-sweep derives from its own normal equations (for the factors it
+    # replaces) against the standalone pass over all entries, on converging factors where
+    # its three terms cancel most: the 1e-5 RMSE bar
+    for keep_old in (True, False):
+        fused = float(eng.half_sweep_users_err(keep_old=keep_old).cpu()[0])
+        fused_rmse = float(np.sqrt(fused / eng.nnz))
+        assert abs(fused_rmse - rmse[-1]) <= 1e-5 * rmse[-1], (fused_rmse, rmse[-1])
+        if keep_old:
+            eng.commit_users()
+        eng.half_sweep_items()
+        rmse.append(eng.train_rmse())
     assert torch.isfinite(eng.U).all() and torch.isfinite(eng.V).all()
     assert not eng.U[:, RANK:].any() and not eng.V[:, RANK:].any()
     # normal equations: (S S^T + alpha n I) x = S r for a block of rows, in fp64 on the host

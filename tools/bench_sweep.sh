@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage: tools/bench_sweep.sh "<label>=<extra bench.py args>" ...   (one bench run per argument)
-# Prints: label, ms/step, user-side ms, item-side ms, error-pass ms, roofline frac, last RMSE.
+# Prints: label, ms/step, user-side ms, item-side ms, roofline frac, last RMSE.
 set -e
 cd "$(dirname "$0")/.."
 for spec in "$@"; do
@@ -11,8 +11,8 @@ for spec in "$@"; do
 import json, os
 d = json.loads(open('/tmp/bench_sweep.json').read().strip().splitlines()[-1])
 r = d['roofline']
-print('%-14s ms/step %.3f  user %.3f  item %.3f  sse %.3f  frac %.3f  rmse %.7f' % (
+print('%-14s ms/step %.3f  user %.3f  item %.3f  frac %.3f  rmse %.7f' % (
     os.environ['LABEL'], d['ms_per_step'], r['user_side']['ms'], r['item_side']['ms'],
-    d['sddmm']['ms'], r['frac'], d['train_rmse']['last']))
+    r['frac'], d['train_rmse']['last']))
 PY
 done
