@@ -574,7 +574,7 @@ struct GjStep<T, KP, KP> {
 // cycles of issue here whatever it does, so halving their number is what pays.  Columns <= P
 // are dead after step P (nothing reads them again), so whole aligned groups of four are
 // updated without masking.  `col` is a wave-private LDS vector of KP elements.
-template <int KP, int P, int CH>
+template <int KP, int P, int CH, int SPCT>
 struct GjStepPk {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -582,6 +582,11 @@ struct GjStepPk {
                                                int lane, float *col) {
         constexpr int G0 = (P + 1) / 4;      // first group of four holding a column > P
         constexpr int NG = KP / 4 - G0;      // groups to update
+        // The broadcast reads return 16 bytes to each of 64 lanes and the LDS of a CU delivers
+        // 128 bytes per cycle to its four SIMDs together, which bounds a solve that fetches
+        // every pivot entry that way.  SPCT percent of the groups therefore take their four
+        // entries through v_readlane into scalar registers instead (vector-ALU issue, no LDS).
+        constexpr int NS = (NG * SPCT + 50) / 100;
         const float u = a[P / 2][P & 1];
         if (lane < KP) col[lane] = u;
         const float d = read_lane(u, P);
@@ -594,10 +599,18 @@ struct GjStepPk {
         bb -= m * zp;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // at most CH groups (4*CH values) of reads in flight, to bound the registers they hold
         const f2 mm = {-m, -m};
 #pragma unroll
-        for (int h0 = 0; h0 < NG; h0 += CH) {
+        for (int h = 0; h < NS; ++h) {
+            const int c = 4 * (G0 + h);
+            const f2 lo = {read_lane(u, c), read_lane(u, c + 1)};
+            const f2 hi = {read_lane(u, c + 2), read_lane(u, c + 3)};
+            a[c / 2] = __builtin_elementwise_fma(mm, lo, a[c / 2]);
+            a[c / 2 + 1] = __builtin_elementwise_fma(mm, hi, a[c / 2 + 1]);
+        }
+        // at most CH groups (4*CH values) of reads in flight, to bound the registers they hold
+#pragma unroll
+        for (int h0 = NS; h0 < NG; h0 += CH) {
             f4 sc[CH];
 #pragma unroll
             for (int g4 = 0; g4 < CH; ++g4)
@@ -614,11 +627,11 @@ struct GjStepPk {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        GjStepPk<KP, P + 1, CH>::run(a, bb, dinv, bad, lane, col);
+        GjStepPk<KP, P + 1, CH, SPCT>::run(a, bb, dinv, bad, lane, col);
     }
 };
-template <int KP, int CH>
-struct GjStepPk<KP, KP, CH> {
+template <int KP, int CH, int SPCT>
+struct GjStepPk<KP, KP, CH, SPCT> {
     typedef float f2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ void run(f2 (&)[KP / 2], float &, float &, int &, int,
                                                float *) {}
@@ -626,7 +639,7 @@ struct GjStepPk<KP, KP, CH> {
 
 // Solve from the accumulators; x_out is the solution component of row `lane`.
 // Returns false when a pivot is not positive.
-template <typename T, int NV, int READS_IN_FLIGHT>
+template <typename T, int NV, int READS_IN_FLIGHT, int SPCT>
 __device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int lane, int rank,
                                          T ridge, T &x_out) {
     constexpr int KP = NV * 16;
@@ -641,11 +654,143 @@ __device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int l
         f2 a2[KP / 2];
 #pragma unroll
         for (int c = 0; c < KP / 2; ++c) a2[c] = f2{a[2 * c], a[2 * c + 1]};
-        GjStepPk<KP, 0, READS_IN_FLIGHT>::run(a2, bb, dinv, bad, lane, stage);  // stage is free
+        GjStepPk<KP, 0, READS_IN_FLIGHT, SPCT>::run(a2, bb, dinv, bad, lane, stage);  // stage is free
     } else {
         GjStep<T, KP, 0>::run(a, bb, dinv, bad, lane);
     }
     x_out = bb * dinv;
+    return bad == 0;
+}
+
+// ---- fp32 solve on the matrix cores, straight from the accumulators (padded rank <= 64) -------
+// The NV x NV tiles of the accumulators are the blocks of the normal matrix in a permuted index
+// order (block e = the dimensions congruent to e modulo NV), each in the matrix core's result
+// layout: lane (g,q), register r = M[4g+r][q].  Two facts make a block elimination possible
+// without moving a single element between lanes:
+//  * fed to v_mfma_f32_16x16x4 as BOTH operands, register s at step s, two tiles X and Y in
+//    that layout give X^T Y (the contraction runs over the row index of both);
+//  * the same registers are the sixteen 4x4 blocks of v_mfma_f32_4x4x1 (block = lane/4,
+//    register = row, lane%4 = column), so a rank-one update of a tile is one such instruction
+//    whose two operands are one value per lane.
+// Per pivot block k: the diagonal tile is inverted in place by sixteen symmetric sweeps (each:
+// pivot row and pivot column entries through two ds_bpermute, one 4x4x1 update, fix-ups of the
+// pivot row and column) giving N = -inv(S_kk); T_kJ = N S_kJ and S_IJ += S_kI^T T_kJ run on the
+// 16x16x4 instruction.  The right-hand side rides along on the vector ALU in two layouts:
+// "column" (lane (.,q) holds v[q]) and "row" (lane (g,.) register r holds v[4g+r]); a product
+// with a tile turns one into the other.  Back substitution uses the stored T_kJ.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
+// sum over the 16 lanes of a row, result in each of them
+__device__ __forceinline__ float row_allreduce(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+// sum over the four rows (lanes with the same q), result in each of them
+__device__ __forceinline__ float col_allreduce(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float bperm(int byte_addr, float v) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ f4 mfma_xty(f4 x, f4 y, f4 c) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], y[s], c, 0, 0, 0);
+    return c;
+}
+
+// tile -> -inverse(tile), in place; bad is set when a pivot is not positive.
+__device__ __forceinline__ void sweep_invert(f4 &a, int lane, int &bad) {
+    const int g = lane >> 4, q = lane & 15;
+    const int addr_row = 4 * q;                   // + 64*gp: lane (gp, q)
+    const int addr_col = 4 * (4 * g + (q & 3));   // + 64*gp: lane (gp, 4g + q%4)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int gp = p >> 2, rp = p & 3;
+        const float src = a[rp];
+        const float rowq = bperm(addr_row + 64 * gp, src);  // A[p][q]
+        const float cola = bperm(addr_col + 64 * gp, src);  // A[p][4g+q%4] = A[4g+q%4][p]
+        const float d = read_lane(src, 16 * gp + p);
+        bad |= (d > 0.0f) ? 0 : 1;
+        const float inv = pivot_rcp(d);
+        const bool pc = q == p;  // this lane holds entries of the pivot column
+        const float a_op = cola * inv;
+        const float b_op = pc ? 0.0f : -rowq;
+        const float sc = pc ? inv : 1.0f;
+        a *= sc;
+        a = __builtin_amdgcn_mfma_f32_4x4x1f32(a_op, b_op, a, 0, 0, 0);
+        const float t = (pc ? -1.0f : rowq) * inv;
+        a[rp] = (g == gp) ? t : a[rp];
+    }
+}
+
+// Solves the NV*16 system held in G (ridge not yet added).  x[k][r] of lane (g,.) is the
+// solution component of dimension (4g+r)*NV + k.  Returns false when a pivot is not positive.
+template <int NV>
+__device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int rank, float ridge,
+                                            float (&x)[NV][4]) {
+    const int q = lane & 15;
+    add_ridge<float, NV>(G, lane, rank, ridge);
+    float y[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) y[e] = col_allreduce(G.b[e]);
+    float tr[NV][4];
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        f4 &nk = G.acc[tri_index(k, k, NV)];
+        sweep_invert(nk, lane, bad);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tr[k][r] = row_allreduce(nk[r] * y[k]);
+        f4 tn[NV];
+#pragma unroll
+        for (int j = k + 1; j < NV; ++j)
+            tn[j] = mfma_xty(nk, G.acc[tri_index(k, j, NV)], f4{0.0f, 0.0f, 0.0f, 0.0f});
+#pragma unroll
+        for (int i = k + 1; i < NV; ++i) {
+            const f4 ski = G.acc[tri_index(k, i, NV)];
+#pragma unroll
+            for (int j = i; j < NV; ++j)
+                G.acc[tri_index(i, j, NV)] = mfma_xty(ski, tn[j], G.acc[tri_index(i, j, NV)]);
+            float part = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += ski[r] * tr[k][r];
+            y[i] += col_allreduce(part);
+        }
+#pragma unroll
+        for (int j = k + 1; j < NV; ++j) G.acc[tri_index(k, j, NV)] = tn[j];
+    }
+    float xc[NV];
+    const int addr_x = 4 * (16 * (q >> 2) + q);  // lane (q/4, q)
+#pragma unroll
+    for (int k = NV - 1; k >= 0; --k) {
+        if (k == NV - 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[k][r] = -tr[k][r];
+        } else {
+            f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = k + 1; j < NV; ++j) acc += G.acc[tri_index(k, j, NV)] * xc[j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[k][r] = row_allreduce(acc[r]) - tr[k][r];
+        }
+        if (k > 0) {  // row -> column layout for the blocks still to come
+            const float c0 = bperm(addr_x, x[k][0]), c1 = bperm(addr_x, x[k][1]);
+            const float c2 = bperm(addr_x, x[k][2]), c3 = bperm(addr_x, x[k][3]);
+            const int rq = q & 3;
+            xc[k] = rq == 0 ? c0 : rq == 1 ? c1 : rq == 2 ? c2 : c3;
+        }
+    }
     return bad == 0;
 }
 
@@ -747,7 +892,9 @@ struct WaveLds {
 // ABLATE selects a diagnostic build used only for timing experiments (env ALSMI_ABLATE, f32
 // rank 64): 1 = accumulate but skip the solve, 2 = solve but skip the accumulation, 3 = eight
 // instead of four broadcast reads in flight per elimination step (more registers, one wave
-// per SIMD fewer), 4 = Gram build on the fp32 MFMA instead of the bf16 matrix cores (both kernels).  The
+// per SIMD fewer), 4 = Gram build on the fp32 MFMA instead of the bf16 matrix cores (both
+// kernels), 5/6/7 = 25/50/75 % of the pivot entries through scalar registers, 8 = the
+// Gauss-Jordan solve of the fp64 path instead of the matrix-core block solve.  The
 // production kernel is the ABLATE = 0 instantiation and contains none of that code.
 // ERR builds also sum (rating - <current vector, neighbour>)^2 over every entry they read: the
 // training error of the factors BEFORE this half-sweep, at no extra memory traffic.
@@ -805,9 +952,29 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_
             continue;
         }
         const T ridge = p.alpha * (T)(end - beg);
-        if constexpr (FAST) {
+        if constexpr (FAST && sizeof(T) == 4 && ABLATE != 8) {
+            float xs[NV][4];
+            const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs);
+            if ((lane & 15) == 0) {
+                const int g = lane >> 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    typedef float vec_t __attribute__((ext_vector_type(NV)));
+                    vec_t v;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        if constexpr (NV == 1) v = ok ? xs[k][r] : 0.0f;
+                        else v[k] = ok ? xs[k][r] : 0.0f;
+                    }
+                    *reinterpret_cast<vec_t *>(out + (4 * g + r) * NV) = v;
+                }
+            }
+            continue;
+        } else if constexpr (FAST) {
             T x;
-            const bool ok = gj_solve<T, NV, ABLATE == 3 ? 8 : 4>(G, Asm, bsm, lane, p.rank, ridge, x);
+            constexpr int SPCT = ABLATE == 5 ? 25 : ABLATE == 6 ? 50 : ABLATE == 7 ? 75 : 0;
+            const bool ok =
+                gj_solve<T, NV, ABLATE == 3 ? 8 : 4, SPCT>(G, Asm, bsm, lane, p.rank, ridge, x);
             if (lane < KP) out[lane] = ok ? x : T(0);
             continue;
         }
@@ -870,6 +1037,10 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, double 
         if (!dump && ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
         if (!dump && ablate == 3) kern = solve_rows_kernel<T, NV, WPB, false, 3>;
         if (!dump && ablate == 4) kern = solve_rows_kernel<T, NV, WPB, false, 4>;
+        if (!dump && ablate == 5) kern = solve_rows_kernel<T, NV, WPB, false, 5>;
+        if (!dump && ablate == 6) kern = solve_rows_kernel<T, NV, WPB, false, 6>;
+        if (!dump && ablate == 7) kern = solve_rows_kernel<T, NV, WPB, false, 7>;
+        if (!dump && ablate == 8) kern = solve_rows_kernel<T, NV, WPB, false, 8>;
         }
     }
     ALSMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
