@@ -87,12 +87,14 @@ struct ErrAcc {
 };
 
 // This lane's share of the row's squared error; the shares of the 64 lanes add up to it.
-// Must run before the ridge goes into the accumulators.  cur_row = the row's current vector
+// Must run before the ridge goes into the accumulators; inv_s2 undoes the scale of the
+// accumulators (1 when they are unscaled).  cur_row = the row's current vector
 // (KP elements).  Tile (e,f), register r of lane (g,q) holds G[crow(g,r)*NV+e][q*NV+f]; an
 // off-diagonal tile stands for its mirror image too.
 template <typename T, int NV>
 __device__ __forceinline__ double row_error_part(const Gram<T, NV> &G, T r2,
-                                                 const T *__restrict__ cur_row, int lane) {
+                                                 const T *__restrict__ cur_row, int lane,
+                                                 T inv_s2) {
     const int g = lane >> 4, q = lane & 15;
     T uc[NV], ur[4][NV];
     load_vec<T, NV>(uc, cur_row + q * NV);
@@ -110,7 +112,7 @@ __device__ __forceinline__ double row_error_part(const Gram<T, NV> &G, T r2,
             for (int r = 0; r < 4; ++r) t += G.acc[tri_index(e, f, NV)][r] * ur[r][e];
             quad += (e == f ? T(1) : T(2)) * t * uc[f];
         }
-    return (double)r2 * 0.0625 - 2.0 * (double)ub + (double)quad;
+    return (double)r2 * 0.0625 - 2.0 * (double)ub + (double)(quad * inv_s2);
 }
 
 // One k=4 MFMA step: four neighbours (one per lane group), all upper tiles.
@@ -290,13 +292,93 @@ __device__ __forceinline__ void gram_block32_split(Gram<float, NV> &G, ErrAcc<fl
         }
 }
 
-// Accumulate entries [beg, end) of one row on the bf16 matrix cores (fp32 data).
-template <int NV, bool ERR>
+// ---- fp32 Gram build on the fp16 matrix cores (two-way split of scaled values) ----------------
+// Rounded to nearest, x*S = h + l with h = fp16(x*S) and l = fp16(x*S - h) leaves an error of
+// 2^-24 |x*S| (|l| <= 2^-12 |x*S|, and its own rounding is relative to l), the precision of an
+// fp32 value, provided l stays in fp16's normal range.  S is a power of two chosen per source
+// table so that max |x| * S lies in [2^13, 2^14): every element larger than max * 2^-16 keeps full
+// precision, smaller ones lose bits only below 2^-29 of the largest.  Then
+// x*y*S^2 = hh' + hl' + lh' up to 2^-24: three v_mfma_f32_16x16x32_f16 per tile and 32
+// neighbours instead of six bf16 ones, and the conversion is 3 vector instructions per element
+// (v_pk_mul_f32, v_cvt_pk_f16_f32 twice, two v_cvt_f32_f16, v_pk_add_f32 per pair) instead of
+// 5.5.  The accumulators hold S^2 * G; the ridge and the right-hand side are scaled to match
+// before the solve.  Operand map as for the bf16 instruction above.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// S from the bit pattern of max |x| over the source table (0 for an all-zero table).
+__device__ __forceinline__ float split_scale(unsigned max_bits) {
+    int e = (int)(max_bits >> 23) - 127;  // floor(log2 max)
+    if (max_bits == 0u || (max_bits >> 23) == 255u) e = 13;
+    e = e < -40 ? -40 : (e > 40 ? 40 : e);
+    return __builtin_bit_cast(float, (unsigned)(127 + 13 - e) << 23);
+}
+
+template <int NV, bool FULL, bool ERR>
+__device__ __forceinline__ void gram_block32_f16(Gram<float, NV> &G, ErrAcc<float, NV, ERR> &E,
+                                                 const float *__restrict__ srcq, int idx, float rv,
+                                                 int off, int valid, int g, float scale) {
+    constexpr int KP = NV * 16;
+    float v[8][NV];
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int t = 8 * g + j;
+        const int id = __shfl(idx, off + t);
+        r[j] = __shfl(rv, off + t);
+        load_vec<float, NV>(v[j], srcq + (int64_t)id * KP);
+        if constexpr (!FULL) {
+            const bool ok = t < valid;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) v[j][e] = ok ? v[j][e] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        E.add(r[j]);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) G.b[e] += r[j] * v[j][e];
+    }
+    f16x8 H[NV], L[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 x = f32x2{v[2 * i][e], v[2 * i + 1][e]} * scale;
+            const f16x2 h = __builtin_convertvector(x, f16x2);
+            const f32x2 rest = x - __builtin_convertvector(h, f32x2);  // exact
+            const f16x2 l = __builtin_convertvector(rest, f16x2);
+            H[e][2 * i] = h[0];
+            H[e][2 * i + 1] = h[1];
+            L[e][2 * i] = l[0];
+            L[e][2 * i + 1] = l[1];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = e; f < NV; ++f) {
+            Mfma<float>::acc_t c = G.acc[tri_index(e, f, NV)];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H[e], L[f], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(L[e], H[f], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H[e], H[f], c, 0, 0, 0);
+            G.acc[tri_index(e, f, NV)] = c;
+        }
+}
+
+// How an instantiation builds the Gram matrix.
+enum { GRAM_NATIVE = 0,  // the MFMA of the data type (fp64; fp32 at padded rank 128)
+       GRAM_BF16X3 = 1,  // fp32 data, exact three-way bf16 split, unscaled accumulators
+       GRAM_F16X2 = 2 }; // fp32 data, scaled two-way fp16 split, accumulators hold S^2 G
+
+// Accumulate entries [beg, end) of one row on the 16-bit matrix cores (fp32 data).
+template <int NV, int MODE, bool ERR>
 __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<float, NV, ERR> &E,
                                                  const int32_t *__restrict__ indices,
                                                  const float *__restrict__ vals,
                                                  const float *__restrict__ src, int64_t beg,
-                                                 int64_t end, int lane) {
+                                                 int64_t end, int lane, float scale) {
     const int g = lane >> 4, q = lane & 15;
     const float *srcq = src + q * NV;
     int idx_n = 0;
@@ -305,6 +387,13 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
         idx_n = indices[beg + lane];
         rv_n = vals[beg + lane];
     }
+    auto block = [&](auto full, int idx, float rv, int off, int valid) {
+        constexpr bool FULL = decltype(full)::value;
+        if constexpr (MODE == GRAM_F16X2)
+            gram_block32_f16<NV, FULL, ERR>(G, E, srcq, idx, rv, off, valid, g, scale);
+        else
+            gram_block32_split<NV, FULL, ERR>(G, E, srcq, idx, rv, off, valid, g);
+    };
     for (int64_t base = beg; base < end; base += WAVE) {
         const int64_t left = end - base;
         const int cnt = left < WAVE ? (int)left : WAVE;
@@ -317,43 +406,61 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
             rv_n = vals[base + WAVE + lane];
         }
         if (cnt >= 32)
-            gram_block32_split<NV, true, ERR>(G, E, srcq, idx, rv, 0, 32, g);
+            block(std::true_type{}, idx, rv, 0, 32);
         else
-            gram_block32_split<NV, false, ERR>(G, E, srcq, idx, rv, 0, cnt, g);
+            block(std::false_type{}, idx, rv, 0, cnt);
         if (cnt == 64)
-            gram_block32_split<NV, true, ERR>(G, E, srcq, idx, rv, 32, 32, g);
+            block(std::true_type{}, idx, rv, 32, 32);
         else if (cnt > 32)
-            gram_block32_split<NV, false, ERR>(G, E, srcq, idx, rv, 32, cnt - 32, g);
+            block(std::false_type{}, idx, rv, 32, cnt - 32);
     }
 }
 
-// Which accumulation an instantiation uses: fp32 data up to padded rank 64 goes to the bf16
-// matrix cores; fp64 keeps its own MFMA, and so does fp32 at padded rank 128, where the three
-// operand sets next to 36 accumulator tiles no longer fit the register file.  FP32_MFMA forces
-// the fp32 MFMA (timing comparisons).
-template <typename T, int NV, bool FP32_MFMA>
-constexpr bool use_split() {
-    return sizeof(T) == 4 && NV <= 4 && !FP32_MFMA;
+// fp32 data up to padded rank 64 goes to the 16-bit matrix cores; fp64 keeps its own MFMA, and
+// so does fp32 at padded rank 128, where the operand sets next to 36 accumulator tiles no
+// longer fit the register file.  The debug dump of the normal equations wants unscaled
+// accumulators and takes the bf16 split.  ABLATE 4 / 10 force the native MFMA / the bf16 split
+// (timing comparisons).
+template <typename T, int NV, int ABLATE, bool DUMP>
+constexpr int gram_mode() {
+    if (sizeof(T) != 4 || NV > 4 || ABLATE == 4) return GRAM_NATIVE;
+    return (DUMP || ABLATE == 10) ? GRAM_BF16X3 : GRAM_F16X2;
 }
 
-template <typename T, int NV, bool SPLIT, bool ERR>
+template <typename T, int NV, int MODE, bool ERR>
 __device__ __forceinline__ void gram_accumulate(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E,
                                                 const int32_t *indices, const T *vals,
                                                 const T *src, int64_t beg, int64_t end,
-                                                int lane) {
-    if constexpr (SPLIT && sizeof(T) == 4)
-        gram_range_split<NV, ERR>(G, E, indices, vals, src, beg, end, lane);
+                                                int lane, float scale) {
+    if constexpr (MODE != GRAM_NATIVE && sizeof(T) == 4)
+        gram_range_split<NV, MODE, ERR>(G, E, indices, vals, src, beg, end, lane, scale);
     else
         gram_range<T, NV, ERR>(G, E, indices, vals, src, beg, end, lane);
 }
 
+// Largest |x| of a table as the bit pattern of a non-negative float (which orders like the
+// unsigned integer), combined with atomicMax into *out (zeroed by the caller).  NaN entries are
+// skipped here and propagate through the arithmetic instead.
+__global__ __launch_bounds__(256) void max_abs_kernel(const float *__restrict__ x, int64_t n4,
+                                                      unsigned *__restrict__ out) {
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const vec_t t = reinterpret_cast<const vec_t *>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
 // ---- kernel 1: partial normal equations of the chunks of long rows ---------------------
 // ERR: also the chunk's sum of squared ratings (last slab slot).
-template <typename T, int NV, bool FP32_MFMA = false, bool ERR = false>
+template <typename T, int NV, int MODE, bool ERR = false>
 __global__ __launch_bounds__(256, (NV == 4 ? 2 : 1)) void gram_chunks_kernel(
     const int64_t *__restrict__ ch_beg, const int64_t *__restrict__ ch_end, int n_chunks,
     const int32_t *__restrict__ indices, const T *__restrict__ vals, const T *__restrict__ src,
-    T *__restrict__ slabs) {
+    const unsigned *__restrict__ max_bits, T *__restrict__ slabs) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (w >= n_chunks) return;
@@ -361,8 +468,9 @@ __global__ __launch_bounds__(256, (NV == 4 ? 2 : 1)) void gram_chunks_kernel(
     G.zero();
     ErrAcc<T, NV, ERR> E;
     E.init();
-    gram_accumulate<T, NV, use_split<T, NV, FP32_MFMA>(), ERR>(G, E, indices, vals, src,
-                                                               ch_beg[w], ch_end[w], lane);
+    float scale = 1.0f;
+    if constexpr (MODE == GRAM_F16X2) scale = split_scale(max_bits[0]);
+    gram_accumulate<T, NV, MODE, ERR>(G, E, indices, vals, src, ch_beg[w], ch_end[w], lane, scale);
     G.store(slabs + (size_t)w * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane, E.sum);
 }
 
@@ -867,6 +975,7 @@ struct SolveArgs {
     const T *vals;
     const T *src;
     const T *slabs;
+    const unsigned *max_bits;  // bit pattern of max |src| (scaled fp16 Gram build only)
     T *dst;
     int rank;
     T alpha;
@@ -890,12 +999,10 @@ struct WaveLds {
 
 // ---- kernel 2: one wave per row — accumulate (or take the row's summed slab), solve ---------
 // ABLATE selects a diagnostic build used only for timing experiments (env ALSMI_ABLATE, f32
-// rank 64): 1 = accumulate but skip the solve, 2 = solve but skip the accumulation, 3 = eight
-// instead of four broadcast reads in flight per elimination step (more registers, one wave
-// per SIMD fewer), 4 = Gram build on the fp32 MFMA instead of the bf16 matrix cores (both
-// kernels), 5/6/7 = 25/50/75 % of the pivot entries through scalar registers, 8 = the
-// Gauss-Jordan solve of the fp64 path instead of the matrix-core block solve.  The
-// production kernel is the ABLATE = 0 instantiation and contains none of that code.
+// rank 64): 1 = accumulate but skip the solve, 2 = solve but skip the accumulation, 4 = Gram
+// build on the fp32 MFMA, 10 = on the bf16 matrix cores with the exact three-way split (both
+// kernels), 8 = the Gauss-Jordan solve of the fp64 path instead of the matrix-core block
+// solve.  The production kernel is the ABLATE = 0 instantiation and contains none of that code.
 // ERR builds also sum (rating - <current vector, neighbour>)^2 over every entry they read: the
 // training error of the factors BEFORE this half-sweep, at no extra memory traffic.
 template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0, bool ERR = false>
@@ -912,6 +1019,10 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_
     T *bsm = Asm + KP * (FAST ? Stage<T, KP < 64 ? KP : 64>::LD : LD);
     T *dsm = bsm + KP;
     const int W = gridDim.x * WPB;
+    constexpr int MODE = gram_mode<T, NV, ABLATE, DUMP>();
+    float scale = 1.0f;
+    if constexpr (MODE == GRAM_F16X2) scale = split_scale(p.max_bits[0]);
+    const T s2 = (T)(scale * scale), inv_s2 = (T)(1.0f / (scale * scale));
     double lane_err = 0.0;  // this lane's share of the squared error of the wave's rows
     for (int t = blockIdx.x * WPB + wl; t < p.n_tasks; t += W) {
         const int row = p.order[t];
@@ -938,11 +1049,16 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_
             // a long row: sum_slabs_kernel left the sum of its chunks in its first slab
             G.add(p.slabs + (size_t)sf * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane, E.sum);
         } else if constexpr (ABLATE != 2) {
-            gram_accumulate<T, NV, use_split<T, NV, ABLATE == 4>(), ERR>(
-                G, E, p.indices, p.vals, p.src, beg, end, lane);
+            gram_accumulate<T, NV, MODE, ERR>(G, E, p.indices, p.vals, p.src, beg, end, lane,
+                                              scale);
         }
         if constexpr (ERR)
-            lane_err += row_error_part<T, NV>(G, E.sum, p.cur + (int64_t)row * KP, lane);
+            lane_err +=
+                row_error_part<T, NV>(G, E.sum, p.cur + (int64_t)row * KP, lane, inv_s2);
+        if constexpr (MODE == GRAM_F16X2) {  // (S^2 A) x = S^2 b
+#pragma unroll
+            for (int e = 0; e < NV; ++e) G.b[e] *= s2;
+        }
         if constexpr (ABLATE == 1) {
             T sum = G.b[0];
 #pragma unroll
@@ -951,7 +1067,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_
             if (lane < KP) out[lane] = sum;
             continue;
         }
-        const T ridge = p.alpha * (T)(end - beg);
+        const T ridge = p.alpha * (T)(end - beg) * s2;
         if constexpr (FAST && sizeof(T) == 4 && ABLATE != 8) {
             float xs[NV][4];
             const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs);
@@ -972,9 +1088,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_
             continue;
         } else if constexpr (FAST) {
             T x;
-            constexpr int SPCT = ABLATE == 5 ? 25 : ABLATE == 6 ? 50 : ABLATE == 7 ? 75 : 0;
-            const bool ok =
-                gj_solve<T, NV, ABLATE == 3 ? 8 : 4, SPCT>(G, Asm, bsm, lane, p.rank, ridge, x);
+            const bool ok = gj_solve<T, NV, 4, 0>(G, Asm, bsm, lane, p.rank, ridge, x);
             if (lane < KP) out[lane] = ok ? x : T(0);
             continue;
         }
@@ -1013,6 +1127,7 @@ struct alsmi_plan {
     size_t slab_bytes;
     double *err_part;  // one squared-error partial per wave of the solve grid
     int err_part_cap;
+    unsigned *max_bits;  // bit pattern of the largest |source factor| of the running call
 };
 
 namespace alsmi {
@@ -1020,6 +1135,12 @@ namespace alsmi {
 static size_t slab_slots(int kp) {
     const int nv = kp / 16;
     return (size_t)(nv * (nv + 1) / 2 * 4 + nv + 1) * WAVE;
+}
+
+// Diagnostic build selected by the environment (fp32, padded rank 64, plain half-sweep only).
+static int ablation() {
+    static const int v = getenv("ALSMI_ABLATE") ? atoi(getenv("ALSMI_ABLATE")) : 0;
+    return v;
 }
 
 template <typename T, int NV, int WPB>
@@ -1031,16 +1152,13 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, double 
     auto kern = dump ? solve_rows_kernel<T, NV, WPB, true> : solve_rows_kernel<T, NV, WPB, false>;
     if (err_out) kern = solve_rows_kernel<T, NV, WPB, false, 0, true>;
     if constexpr (sizeof(T) == 4 && NV == 4) {
-        if (!err_out) {
-        static const int ablate = getenv("ALSMI_ABLATE") ? atoi(getenv("ALSMI_ABLATE")) : 0;
-        if (!dump && ablate == 1) kern = solve_rows_kernel<T, NV, WPB, false, 1>;
-        if (!dump && ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
-        if (!dump && ablate == 3) kern = solve_rows_kernel<T, NV, WPB, false, 3>;
-        if (!dump && ablate == 4) kern = solve_rows_kernel<T, NV, WPB, false, 4>;
-        if (!dump && ablate == 5) kern = solve_rows_kernel<T, NV, WPB, false, 5>;
-        if (!dump && ablate == 6) kern = solve_rows_kernel<T, NV, WPB, false, 6>;
-        if (!dump && ablate == 7) kern = solve_rows_kernel<T, NV, WPB, false, 7>;
-        if (!dump && ablate == 8) kern = solve_rows_kernel<T, NV, WPB, false, 8>;
+        const int ablate = ablation();
+        if (!dump && !err_out) {
+            if (ablate == 1) kern = solve_rows_kernel<T, NV, WPB, false, 1>;
+            if (ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
+            if (ablate == 4) kern = solve_rows_kernel<T, NV, WPB, false, 4>;
+            if (ablate == 8) kern = solve_rows_kernel<T, NV, WPB, false, 8>;
+            if (ablate == 10) kern = solve_rows_kernel<T, NV, WPB, false, 10>;
         }
     }
     ALSMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1070,19 +1188,41 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, double 
 
 template <typename T, int NV, int WPB>
 static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
-                          const void *vals, const void *src, void *dst, double alpha, void *A_out,
-                          void *b_out, const void *cur, double *err_out, hipStream_t st) {
+                          const void *vals, const void *src, int64_t n_src, void *dst,
+                          double alpha, void *A_out, void *b_out, const void *cur,
+                          double *err_out, hipStream_t st) {
+    const bool dump = A_out != nullptr;
+    int mode = GRAM_NATIVE;
+    if constexpr (sizeof(T) == 4 && NV <= 4) {
+        mode = dump ? GRAM_BF16X3 : GRAM_F16X2;
+        if constexpr (NV == 4) {
+            if (!dump && !err_out && ablation() == 4) mode = GRAM_NATIVE;
+            if (!dump && !err_out && ablation() == 10) mode = GRAM_BF16X3;
+        }
+        if (mode == GRAM_F16X2) {
+            // scale of the fp16 split: the largest magnitude of the source table
+            ALSMI_HIP_CHECK(hipMemsetAsync(pl->max_bits, 0, sizeof(unsigned), st));
+            const int64_t n4 = n_src * (int64_t)(NV * 16) / 4;
+            int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 4 * (int64_t)pl->cu_count);
+            if (blocks < 1) blocks = 1;
+            hipLaunchKernelGGL(max_abs_kernel, dim3(blocks), dim3(256), 0, st,
+                               static_cast<const float *>(src), n4, pl->max_bits);
+            ALSMI_HIP_CHECK(hipGetLastError());
+        }
+    }
     if (pl->n_chunks > 0) {
         const int grid = (pl->n_chunks + 3) / 4;
-        auto chunks = gram_chunks_kernel<T, NV, false>;
-        if (err_out) chunks = gram_chunks_kernel<T, NV, false, true>;
-        if constexpr (sizeof(T) == 4 && NV == 4) {
-            static const int ablate = getenv("ALSMI_ABLATE") ? atoi(getenv("ALSMI_ABLATE")) : 0;
-            if (ablate == 4 && !err_out) chunks = gram_chunks_kernel<T, NV, true>;
+        auto chunks = gram_chunks_kernel<T, NV, GRAM_NATIVE, false>;
+        if (err_out) chunks = gram_chunks_kernel<T, NV, GRAM_NATIVE, true>;
+        if constexpr (sizeof(T) == 4 && NV <= 4) {
+            if (mode == GRAM_F16X2)
+                chunks = err_out ? gram_chunks_kernel<T, NV, GRAM_F16X2, true>
+                                 : gram_chunks_kernel<T, NV, GRAM_F16X2, false>;
+            if (mode == GRAM_BF16X3) chunks = gram_chunks_kernel<T, NV, GRAM_BF16X3, false>;
         }
         hipLaunchKernelGGL(chunks, dim3(grid), dim3(256), 0, st, pl->ch_beg, pl->ch_end,
                            pl->n_chunks, indices, static_cast<const T *>(vals),
-                           static_cast<const T *>(src), static_cast<T *>(pl->slabs));
+                           static_cast<const T *>(src), pl->max_bits, static_cast<T *>(pl->slabs));
         ALSMI_HIP_CHECK(hipGetLastError());
         const int slab_elems = Gram<T, NV>::SLAB_SLOTS * WAVE;
         const int per_row = (slab_elems + 255) / 256;
@@ -1101,6 +1241,7 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     a.vals = static_cast<const T *>(vals);
     a.src = static_cast<const T *>(src);
     a.slabs = static_cast<const T *>(pl->slabs);
+    a.max_bits = pl->max_bits;
     a.dst = static_cast<T *>(dst);
     a.rank = pl->rank;
     a.alpha = (T)alpha;
@@ -1109,15 +1250,15 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     a.row_begin = pl->row_begin;
     a.cur = static_cast<const T *>(cur);
     a.err_part = pl->err_part;
-    return launch_solve<T, NV, WPB>(pl, a, A_out != nullptr, err_out, st);
+    return launch_solve<T, NV, WPB>(pl, a, dump, err_out, st);
 }
 
 static int dispatch(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
-                    const void *vals, const void *src, void *dst, double alpha, void *A_out,
-                    void *b_out, const void *cur, double *err_out, hipStream_t st) {
-#define ALSMI_CASE(T, NV, WPB)                                                                  \
-    return run_half_sweep<T, NV, WPB>(pl, indptr, indices, vals, src, dst, alpha, A_out, b_out, \
-                                      cur, err_out, st)
+                    const void *vals, const void *src, int64_t n_src, void *dst, double alpha,
+                    void *A_out, void *b_out, const void *cur, double *err_out, hipStream_t st) {
+#define ALSMI_CASE(T, NV, WPB)                                                                \
+    return run_half_sweep<T, NV, WPB>(pl, indptr, indices, vals, src, n_src, dst, alpha, A_out, \
+                                      b_out, cur, err_out, st)
     if (pl->dtype == ALSMI_F32) {
         switch (pl->kp) {
             case 16: ALSMI_CASE(float, 1, 4);
@@ -1218,6 +1359,7 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     if (e == hipSuccess) e = upload((void **)&pl->ch_beg, ch_beg.data(), ch_beg.size() * 8);
     if (e == hipSuccess) e = upload((void **)&pl->ch_end, ch_end.data(), ch_end.size() * 8);
     if (e == hipSuccess) e = upload(&pl->slabs, nullptr, pl->slab_bytes);
+    if (e == hipSuccess) e = upload((void **)&pl->max_bits, nullptr, sizeof(unsigned));
     pl->err_part_cap = pl->cu_count * 64;
     if (e == hipSuccess)
         e = upload((void **)&pl->err_part, nullptr, (size_t)pl->err_part_cap * sizeof(double));
@@ -1239,6 +1381,7 @@ int alsmi_plan_destroy(alsmi_plan *pl) {
     (void)hipFree(pl->ch_end);
     (void)hipFree(pl->slabs);
     (void)hipFree(pl->err_part);
+    (void)hipFree(pl->max_bits);
     delete pl;
     return ALSMI_OK;
 }
@@ -1270,8 +1413,8 @@ int alsmi_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *indic
     if (rc != ALSMI_OK) return rc;
     if (pl->n_tasks == 0) return ALSMI_OK;
     ALSMI_REQUIRE(dst_factors, "alsmi_half_sweep: null destination");
-    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, dst_factors, alpha, nullptr,
-                           nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
+    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, n_src, dst_factors, alpha,
+                           nullptr, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int alsmi_half_sweep_err(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
@@ -1287,8 +1430,8 @@ int alsmi_half_sweep_err(alsmi_plan *pl, const int64_t *indptr, const int32_t *i
         return ALSMI_OK;
     }
     ALSMI_REQUIRE(dst_factors && cur_factors, "alsmi_half_sweep_err: null factor table");
-    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, dst_factors, alpha, nullptr,
-                           nullptr, cur_factors, sse_out, static_cast<hipStream_t>(stream));
+    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, n_src, dst_factors, alpha,
+                           nullptr, nullptr, cur_factors, sse_out, static_cast<hipStream_t>(stream));
 }
 
 int alsmi_normal_equations(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
@@ -1299,8 +1442,8 @@ int alsmi_normal_equations(alsmi_plan *pl, const int64_t *indptr, const int32_t 
     if (rc != ALSMI_OK) return rc;
     if (pl->n_tasks == 0) return ALSMI_OK;
     ALSMI_REQUIRE(A_out && b_out, "alsmi_normal_equations: null output");
-    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, nullptr, alpha, A_out, b_out,
-                           nullptr, nullptr, static_cast<hipStream_t>(stream));
+    return alsmi::dispatch(pl, indptr, indices, vals, src_factors, n_src, nullptr, alpha, A_out,
+                           b_out, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"
