@@ -95,23 +95,26 @@ template <typename T, int NV>
 __device__ __forceinline__ double row_error_part(const Gram<T, NV> &G, T r2,
                                                  const T *__restrict__ cur_row, int lane,
                                                  T inv_s2) {
+    asm volatile("" : "+v"(lane));  // derive the lane constants here, not outside the row loop
     const int g = lane >> 4, q = lane & 15;
-    T uc[NV], ur[4][NV];
+    T uc[NV];
     load_vec<T, NV>(uc, cur_row + q * NV);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) load_vec<T, NV>(ur[r], cur_row + Mfma<T>::crow(g, r) * NV);
     T ub = T(0), quad = T(0);
 #pragma unroll
     for (int e = 0; e < NV; ++e) ub += G.b[e] * uc[e];
 #pragma unroll
-    for (int e = 0; e < NV; ++e)
+    for (int e = 0; e < NV; ++e) {
+        T ur[4];  // u at the tile rows of this lane, dimension class e
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ur[r] = cur_row[Mfma<T>::crow(g, r) * NV + e];
 #pragma unroll
         for (int f = e; f < NV; ++f) {
             T t = T(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t += G.acc[tri_index(e, f, NV)][r] * ur[r][e];
+            for (int r = 0; r < 4; ++r) t += G.acc[tri_index(e, f, NV)][r] * ur[r];
             quad += (e == f ? T(1) : T(2)) * t * uc[f];
         }
+    }
     return (double)r2 * 0.0625 - 2.0 * (double)ub + (double)(quad * inv_s2);
 }
 
@@ -317,17 +320,20 @@ __device__ __forceinline__ float split_scale(unsigned max_bits) {
 
 template <int NV, bool FULL, bool ERR>
 __device__ __forceinline__ void gram_block32_f16(Gram<float, NV> &G, ErrAcc<float, NV, ERR> &E,
-                                                 const float *__restrict__ srcq, int idx, float rv,
-                                                 int off, int valid, int g, float scale) {
+                                                 const float *__restrict__ src, unsigned qoff,
+                                                 int idx, float rv, int off, int valid, int g,
+                                                 float scale) {
     constexpr int KP = NV * 16;
     float v[8][NV];
     float r[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int t = 8 * g + j;
-        const int id = __shfl(idx, off + t);
+        const unsigned id = (unsigned)__shfl(idx, off + t);
         r[j] = __shfl(rv, off + t);
-        load_vec<float, NV>(v[j], srcq + (int64_t)id * KP);
+        // uniform base + 32-bit byte offset (the host checks that the table is below 4 GiB)
+        load_vec<float, NV>(v[j], reinterpret_cast<const float *>(
+                                      reinterpret_cast<const char *>(src) + (id * (KP * 4u) + qoff)));
         if constexpr (!FULL) {
             const bool ok = t < valid;
 #pragma unroll
@@ -340,17 +346,52 @@ __device__ __forceinline__ void gram_block32_f16(Gram<float, NV> &G, ErrAcc<floa
 #pragma unroll
         for (int e = 0; e < NV; ++e) G.b[e] += r[j] * v[j][e];
     }
+    // The packed fp32 instructions work on the register pairs a load delivers (two dimensions
+    // of one neighbour); the fp16 packs join two neighbours of one dimension, which the
+    // conversion instructions take from any two registers.  Two neighbours at a time, so
+    // that few temporaries are live.
     f16x8 H[NV], L[NV];
 #pragma unroll
-    for (int e = 0; e < NV; ++e) {
+    for (int i = 0; i < 4; ++i) {
+        float xs[2][NV], hf[2][NV];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x2 x = f32x2{v[2 * i][e], v[2 * i + 1][e]} * scale;
-            const f16x2 h = __builtin_convertvector(x, f16x2);
-            const f32x2 rest = x - __builtin_convertvector(h, f32x2);  // exact
-            const f16x2 l = __builtin_convertvector(rest, f16x2);
+        for (int jj = 0; jj < 2; ++jj) {
+            if constexpr (NV >= 2) {
+#pragma unroll
+                for (int e = 0; e < NV; e += 2) {
+                    const f32x2 x = f32x2{v[2 * i + jj][e], v[2 * i + jj][e + 1]} * scale;
+                    xs[jj][e] = x[0];
+                    xs[jj][e + 1] = x[1];
+                }
+            } else {
+                xs[jj][0] = v[2 * i + jj][0] * scale;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const f16x2 h = __builtin_convertvector(f32x2{xs[0][e], xs[1][e]}, f16x2);
             H[e][2 * i] = h[0];
             H[e][2 * i + 1] = h[1];
+            hf[0][e] = (float)h[0];
+            hf[1][e] = (float)h[1];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if constexpr (NV >= 2) {
+#pragma unroll
+                for (int e = 0; e < NV; e += 2) {
+                    const f32x2 rest =
+                        f32x2{xs[jj][e], xs[jj][e + 1]} - f32x2{hf[jj][e], hf[jj][e + 1]};
+                    xs[jj][e] = rest[0];  // exact
+                    xs[jj][e + 1] = rest[1];
+                }
+            } else {
+                xs[jj][0] -= hf[jj][0];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const f16x2 l = __builtin_convertvector(f32x2{xs[0][e], xs[1][e]}, f16x2);
             L[e][2 * i] = l[0];
             L[e][2 * i + 1] = l[1];
         }
@@ -390,7 +431,8 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
     auto block = [&](auto full, int idx, float rv, int off, int valid) {
         constexpr bool FULL = decltype(full)::value;
         if constexpr (MODE == GRAM_F16X2)
-            gram_block32_f16<NV, FULL, ERR>(G, E, srcq, idx, rv, off, valid, g, scale);
+            gram_block32_f16<NV, FULL, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv, off, valid,
+                                            g, scale);
         else
             gram_block32_split<NV, FULL, ERR>(G, E, srcq, idx, rv, off, valid, g);
     };
@@ -454,10 +496,15 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const float *__restrict__ 
     if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
 }
 
+// Waves per SIMD the fp32 rank-64 kernels are compiled for (register budget 512 / waves).
+#ifndef SOLVE_MIN_WAVES
+#define SOLVE_MIN_WAVES 3
+#endif
+
 // ---- kernel 1: partial normal equations of the chunks of long rows ---------------------
 // ERR: also the chunk's sum of squared ratings (last slab slot).
 template <typename T, int NV, int MODE, bool ERR = false>
-__global__ __launch_bounds__(256, (NV == 4 ? 2 : 1)) void gram_chunks_kernel(
+__global__ __launch_bounds__(256, (NV == 4 ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES : 2) : 1)) void gram_chunks_kernel(
     const int64_t *__restrict__ ch_beg, const int64_t *__restrict__ ch_end, int n_chunks,
     const int32_t *__restrict__ indices, const T *__restrict__ vals, const T *__restrict__ src,
     const unsigned *__restrict__ max_bits, T *__restrict__ slabs) {
@@ -773,19 +820,24 @@ __device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int l
 // ---- fp32 solve on the matrix cores, straight from the accumulators (padded rank <= 64) -------
 // The NV x NV tiles of the accumulators are the blocks of the normal matrix in a permuted index
 // order (block e = the dimensions congruent to e modulo NV), each in the matrix core's result
-// layout: lane (g,q), register r = M[4g+r][q].  Two facts make a block elimination possible
-// without moving a single element between lanes:
+// layout: lane (g,q), register r = M[4g+r][q].  Three facts make a block LDL^T factorisation
+// possible without an LDS transposition stage:
 //  * fed to v_mfma_f32_16x16x4 as BOTH operands, register s at step s, two tiles X and Y in
 //    that layout give X^T Y (the contraction runs over the row index of both);
 //  * the same registers are the sixteen 4x4 blocks of v_mfma_f32_4x4x1 (block = lane/4,
-//    register = row, lane%4 = column), so a rank-one update of a tile is one such instruction
-//    whose two operands are one value per lane.
-// Per pivot block k: the diagonal tile is inverted in place by sixteen symmetric sweeps (each:
-// pivot row and pivot column entries through two ds_bpermute, one 4x4x1 update, fix-ups of the
-// pivot row and column) giving N = -inv(S_kk); T_kJ = N S_kJ and S_IJ += S_kI^T T_kJ run on the
-// 16x16x4 instruction.  The right-hand side rides along on the vector ALU in two layouts:
-// "column" (lane (.,q) holds v[q]) and "row" (lane (g,.) register r holds v[4g+r]); a product
-// with a tile turns one into the other.  Back substitution uses the stored T_kJ.
+//    register = row, lane%4 = column), so adding a multiple of one tile row to all the others
+//    (one elimination step) is one such instruction whose operands are one value per lane;
+//  * row p of a tile sits in one register of the 16 lanes (p/4, .), so one ds_bpermute hands it
+//    to every lane, indexed by the lane's column or by the row the lane feeds to the 4x4x1.
+// Per pivot block k, sixteen elimination steps (rows below the pivot only; the multipliers come
+// from row p through the symmetry of the trailing block) are applied to the whole block row
+// [S_kk | S_kJ, J > k | R]: R starts as the identity and ends as inv(L_kk) (its last column,
+// which no row operation changes, carries the block's right-hand side instead), S_kJ becomes
+// Z_J = inv(L_kk) S_kJ.  The trailing
+// blocks then take S_IJ -= Z_I^T D^-1 Z_J on the 16x16x4 instruction.  No Schur complement is
+// ever inverted, so the error behaves like that of a Cholesky solve.  Vectors live in two
+// layouts, "column" (lane (.,q) holds v[q]) and "row" (lane (g,.) register r holds v[4g+r]); a
+// product with a tile turns one into the other.
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL>
@@ -811,95 +863,131 @@ __device__ __forceinline__ float bperm(int byte_addr, float v) {
     return __builtin_bit_cast(float,
                               __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
+// When the accumulator input of an fp32 matrix instruction dies at that instruction, the
+// compiler gives the result other registers and is free to reuse the input's registers in the
+// very next vector instruction; it pads nothing there for this instruction class on gfx950.
+// Measured on MI355X: results then change from run to run in about one row in 10^5 (the
+// matrix instruction reads its accumulator input over several cycles, later when the pipe is
+// contended).  A scheduling fence plus NOPS+1 idle issue slots after each group of such
+// instructions removes it; the fp32 matrix instructions share the vector ALU anyway, so the
+// fence costs no overlap.
+template <int NOPS>
+__device__ __forceinline__ void mfma_f32_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop %0" ::"n"(NOPS));
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ f4 mfma_xty(f4 x, f4 y, f4 c) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], y[s], c, 0, 0, 0);
+    mfma_f32_fence<7>();
     return c;
 }
 
-// tile -> -inverse(tile), in place; bad is set when a pivot is not positive.
-__device__ __forceinline__ void sweep_invert(f4 &a, int lane, int &bad) {
-    const int g = lane >> 4, q = lane & 15;
-    const int addr_row = 4 * q;                   // + 64*gp: lane (gp, q)
-    const int addr_col = 4 * (4 * g + (q & 3));   // + 64*gp: lane (gp, 4g + q%4)
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int gp = p >> 2, rp = p & 3;
-        const float src = a[rp];
-        const float rowq = bperm(addr_row + 64 * gp, src);  // A[p][q]
-        const float cola = bperm(addr_col + 64 * gp, src);  // A[p][4g+q%4] = A[4g+q%4][p]
-        const float d = read_lane(src, 16 * gp + p);
-        bad |= (d > 0.0f) ? 0 : 1;
-        const float inv = pivot_rcp(d);
-        const bool pc = q == p;  // this lane holds entries of the pivot column
-        const float a_op = cola * inv;
-        const float b_op = pc ? 0.0f : -rowq;
-        const float sc = pc ? inv : 1.0f;
-        a *= sc;
-        a = __builtin_amdgcn_mfma_f32_4x4x1f32(a_op, b_op, a, 0, 0, 0);
-        const float t = (pc ? -1.0f : rowq) * inv;
-        a[rp] = (g == gp) ? t : a[rp];
-    }
-}
-
-// Solves the NV*16 system held in G (ridge not yet added).  x[k][r] of lane (g,.) is the
-// solution component of dimension (4g+r)*NV + k.  Returns false when a pivot is not positive.
+// Solves the NV*16 system held in G (ridge not yet added).  xc[k] of lane (.,q) is the solution
+// component of dimension q*NV + k.  Returns false when a pivot is not positive or the result is
+// not finite.
 template <int NV>
 __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int rank, float ridge,
-                                            float (&x)[NV][4]) {
-    const int q = lane & 15;
+                                            float (&xc)[NV]) {
+    // The lane-dependent constants below are cheap to derive; hiding the lane id from the
+    // optimiser keeps them from being hoisted out of the row loop, where they would occupy
+    // registers (or spill slots) throughout the accumulation.
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, q = lane & 15;
+    const int irow = 4 * g + (q & 3);  // the tile row this lane feeds to the 4x4x1 instruction
+    const int addr_row = 4 * q;        // + 64*gp: lane (gp, q)
+    const int addr_col = 4 * irow;     // + 64*gp: lane (gp, irow)
     add_ridge<float, NV>(G, lane, rank, ridge);
     float y[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) y[e] = col_allreduce(G.b[e]);
-    float tr[NV][4];
+    // Per pivot block, kept for the back substitution: D^-1 inv(L_kk) (rows scaled) and
+    // z_k = inv(L_kk) y_k in the row layout.
+    f4 rs[NV], zr[NV];
     int bad = 0;
+    const bool last_col = q == 15;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        f4 &nk = G.acc[tri_index(k, k, NV)];
-        sweep_invert(nk, lane, bad);
+        // R starts as the identity.  Its last column stays e_15 whatever the row operations, so
+        // it carries the right-hand side instead: the same operations turn y into inv(L) y.
+        f4 rt, dv = {1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tr[k][r] = row_allreduce(nk[r] * y[k]);
-        f4 tn[NV];
+        for (int r = 0; r < 4; ++r) {
+            const float yrow = bperm(4 * (4 * g + r), y[k]);  // column -> row layout
+            rt[r] = last_col ? yrow : ((4 * g + r == q) ? 1.0f : 0.0f);
+        }
 #pragma unroll
-        for (int j = k + 1; j < NV; ++j)
-            tn[j] = mfma_xty(nk, G.acc[tri_index(k, j, NV)], f4{0.0f, 0.0f, 0.0f, 0.0f});
+        for (int p = 0; p < 16; ++p) {
+            const int gp = p >> 2, rp = p & 3;
+            f4 &a = G.acc[tri_index(k, k, NV)];
+            const float src = a[rp];
+            const float cola = bperm(addr_col + 64 * gp, src);  // A[p][irow] = A[irow][p]
+            const float d = read_lane(src, 16 * gp + p);
+            const float inv = __builtin_amdgcn_rcpf(d);  // 1 ulp; a multiplier needs no more
+            const float m = (irow > p) ? -cola * inv : 0.0f;
+            // all row fetches of the step first, so that their latencies overlap
+            float rows[NV + 1];
+#pragma unroll
+            for (int j = k; j < NV; ++j)
+                rows[j] = bperm(addr_row + 64 * gp, G.acc[tri_index(k, j, NV)][rp]);
+            rows[NV] = bperm(addr_row + 64 * gp, rt[rp]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = k; j < NV; ++j) {
+                f4 &t = G.acc[tri_index(k, j, NV)];
+                t = __builtin_amdgcn_mfma_f32_4x4x1f32(m, rows[j], t, 0, 0, 0);
+            }
+            rt = __builtin_amdgcn_mfma_f32_4x4x1f32(m, rows[NV], rt, 0, 0, 0);
+            mfma_f32_fence<1>();
+            dv[rp] = (g == gp) ? inv : dv[rp];
+        }
+        // every pivot positive and finite <=> every reciprocal positive and finite
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= (dv[r] > 0.0f && dv[r] < INFINITY) ? 0 : 1;
+        f4 dz;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            zr[k][r] = bperm(4 * (16 * g + 15), rt[r]);  // z from lane 15 of each row
+            dz[r] = dv[r] * zr[k][r];
+            const float rtrue = last_col ? ((4 * g + r == 15) ? 1.0f : 0.0f) : rt[r];
+            rs[k][r] = dv[r] * rtrue;
+        }
+        f4 nz[NV];
+#pragma unroll
+        for (int j = k + 1; j < NV; ++j) nz[j] = -dv * G.acc[tri_index(k, j, NV)];
 #pragma unroll
         for (int i = k + 1; i < NV; ++i) {
-            const f4 ski = G.acc[tri_index(k, i, NV)];
+            const f4 zi = G.acc[tri_index(k, i, NV)];
 #pragma unroll
             for (int j = i; j < NV; ++j)
-                G.acc[tri_index(i, j, NV)] = mfma_xty(ski, tn[j], G.acc[tri_index(i, j, NV)]);
+                G.acc[tri_index(i, j, NV)] = mfma_xty(zi, nz[j], G.acc[tri_index(i, j, NV)]);
             float part = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part += ski[r] * tr[k][r];
-            y[i] += col_allreduce(part);
+            for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
+            y[i] -= col_allreduce(part);
         }
-#pragma unroll
-        for (int j = k + 1; j < NV; ++j) G.acc[tri_index(k, j, NV)] = tn[j];
     }
-    float xc[NV];
-    const int addr_x = 4 * (16 * (q >> 2) + q);  // lane (q/4, q)
+    // x_k = inv(L_kk)^T D^-1 (z_k - sum_J Z_kJ x_J)
+    float chk = 0.0f;
 #pragma unroll
     for (int k = NV - 1; k >= 0; --k) {
-        if (k == NV - 1) {
+        f4 rhs = zr[k];
+        if (k < NV - 1) {
+            f4 w = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[k][r] = -tr[k][r];
-        } else {
-            f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = k + 1; j < NV; ++j) w += G.acc[tri_index(k, j, NV)] * xc[j];
 #pragma unroll
-            for (int j = k + 1; j < NV; ++j) acc += G.acc[tri_index(k, j, NV)] * xc[j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[k][r] = row_allreduce(acc[r]) - tr[k][r];
+            for (int r = 0; r < 4; ++r) rhs[r] -= row_allreduce(w[r]);
         }
-        if (k > 0) {  // row -> column layout for the blocks still to come
-            const float c0 = bperm(addr_x, x[k][0]), c1 = bperm(addr_x, x[k][1]);
-            const float c2 = bperm(addr_x, x[k][2]), c3 = bperm(addr_x, x[k][3]);
-            const int rq = q & 3;
-            xc[k] = rq == 0 ? c0 : rq == 1 ? c1 : rq == 2 ? c2 : c3;
-        }
+        float part = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += rs[k][r] * rhs[r];
+        xc[k] = col_allreduce(part);
+        chk += fabsf(xc[k]);
     }
-    return bad == 0;
+    return !__any(bad != 0 || !(chk < INFINITY));
 }
 
 // Generic in-LDS Cholesky + solve for any KP (two rows per lane at KP = 128).  Works on the
@@ -1006,7 +1094,7 @@ struct WaveLds {
 // ERR builds also sum (rating - <current vector, neighbour>)^2 over every entry they read: the
 // training error of the factors BEFORE this half-sweep, at no extra memory traffic.
 template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0, bool ERR = false>
-__global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_rows_kernel(
+__global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES : 2) : 1)) void solve_rows_kernel(
     SolveArgs<T> p) {
     constexpr int KP = NV * 16;
     constexpr int LD = Slab<T, KP>::LD;
@@ -1040,6 +1128,14 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_
             }
             continue;
         }
+        if constexpr (ERR) {
+            // the row's current vector goes to the wave's LDS area now, so that the error
+            // terms after the accumulation do not wait on memory
+            const T *cur_row = p.cur + (int64_t)row * KP;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+                if (lane + 64 * rr < KP) Asm[lane + 64 * rr] = cur_row[lane + 64 * rr];
+        }
         Gram<T, NV> G;
         G.zero();
         const int sf = p.slab_first[t];
@@ -1052,9 +1148,11 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_
             gram_accumulate<T, NV, MODE, ERR>(G, E, p.indices, p.vals, p.src, beg, end, lane,
                                               scale);
         }
-        if constexpr (ERR)
-            lane_err +=
-                row_error_part<T, NV>(G, E.sum, p.cur + (int64_t)row * KP, lane, inv_s2);
+        if constexpr (ERR) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            lane_err += row_error_part<T, NV>(G, E.sum, Asm, lane, inv_s2);
+        }
         if constexpr (MODE == GRAM_F16X2) {  // (S^2 A) x = S^2 b
 #pragma unroll
             for (int e = 0; e < NV; ++e) G.b[e] *= s2;
@@ -1069,21 +1167,17 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? 2 : 1)) void solve_
         }
         const T ridge = p.alpha * (T)(end - beg) * s2;
         if constexpr (FAST && sizeof(T) == 4 && ABLATE != 8) {
-            float xs[NV][4];
+            float xs[NV];
             const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs);
-            if ((lane & 15) == 0) {
-                const int g = lane >> 4;
+            if (lane < 16) {
+                typedef float vec_t __attribute__((ext_vector_type(NV)));
+                vec_t v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    typedef float vec_t __attribute__((ext_vector_type(NV)));
-                    vec_t v;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        if constexpr (NV == 1) v = ok ? xs[k][r] : 0.0f;
-                        else v[k] = ok ? xs[k][r] : 0.0f;
-                    }
-                    *reinterpret_cast<vec_t *>(out + (4 * g + r) * NV) = v;
+                for (int k = 0; k < NV; ++k) {
+                    if constexpr (NV == 1) v = ok ? xs[k] : 0.0f;
+                    else v[k] = ok ? xs[k] : 0.0f;
                 }
+                *reinterpret_cast<vec_t *>(out + lane * NV) = v;
             }
             continue;
         } else if constexpr (FAST) {
@@ -1200,6 +1294,9 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
             if (!dump && !err_out && ablation() == 10) mode = GRAM_BF16X3;
         }
         if (mode == GRAM_F16X2) {
+            ALSMI_REQUIRE(n_src * (int64_t)(NV * 16) * 4 <= (int64_t)UINT32_MAX,
+                          "half-sweep: an fp32 source table of %lld rows exceeds 4 GiB",
+                          (long long)n_src);
             // scale of the fp16 split: the largest magnitude of the source table
             ALSMI_HIP_CHECK(hipMemsetAsync(pl->max_bits, 0, sizeof(unsigned), st));
             const int64_t n4 = n_src * (int64_t)(NV * 16) / 4;

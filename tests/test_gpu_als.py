@@ -125,6 +125,31 @@ def test_half_sweep_with_error_of_replaced_factors(gpu, case, dtype):
     plan.close()
 
 
+@pytest.mark.parametrize('dtype,rank', [('float32', 64), ('float32', 20), ('float64', 64)])
+def test_half_sweep_is_reproducible(gpu, dtype, rank):
+    """The same half-sweep run three times gives bit-identical factors and error sums (fixed
+    summation order, no timing-dependent path), with long rows cut into chunks included."""
+    device, torch = gpu
+    from alsmi import device as dev
+    P = random_problem(77, 6000, 900, 400000, rank, long_row=(17, 850))
+    side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], 6000, 900, dtype, device)
+    plan = dev.SweepPlan(side, rank, chunk=256)
+    assert plan.info()['n_chunks'] > 1
+    V = dev.factors_to_device(P['V'], dtype, device)
+    U0 = dev.factors_to_device(P['U'], dtype, device)
+    outs, sses = [], []
+    for _ in range(3):
+        a = torch.zeros_like(U0)
+        plan.half_sweep(V, a, 0.1)
+        b = torch.zeros_like(U0)
+        sses.append(float(plan.half_sweep_err(V, U0, b, 0.1).cpu()[0]))
+        outs.append((a, b))
+    for a, b in outs[1:]:
+        assert torch.equal(a, outs[0][0]) and torch.equal(b, outs[0][1])
+    assert sses[1] == sses[0] and sses[2] == sses[0]
+    plan.close()
+
+
 def test_half_sweep_singular_gives_zeros(gpu):
     """A = 0 (zero source factors, alpha = 0): the reference's inv() raises
     LinAlgError and the row becomes zeros (src/als.py:246-249)."""

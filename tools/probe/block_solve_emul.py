@@ -122,6 +122,74 @@ def block_solve(tiles, ycol, NV, dtype=np.float32):
     return xr, ok
 
 
+def swizzle_lane15(v):
+    """ds_swizzle, bit mode, and 0x10 or 0x0F: every lane reads lane 15 of its row."""
+    return v[(LANES & 0x30) | 15]
+
+
+def block_solve_ldl(tiles, ycol, NV, dtype=np.float32):
+    """Stable variant: block LDL^T.  Per pivot block the sixteen elimination steps are applied,
+    as row operations, to the whole block row [S_kk | S_kJ ... | R] (R starts as the identity
+    and ends as inv(L_kk); its last column, which no row operation changes, carries the
+    right-hand side), every tile updated by one 4x4x1 instruction per step; the trailing blocks
+    then get S_IJ -= Z_I^T D^-1 Z_J on the 16x16x4 instruction.  No inverse of a Schur
+    complement is ever formed.  Returns xc[k]: [64] column layout, lane (.,q) = x_k[q]."""
+    S = {k: v.astype(dtype).copy() for k, v in tiles.items()}
+    y = [v.astype(dtype).copy() for v in ycol]
+    irow = 4 * G + (Q & 3)
+    last_col = Q == 15
+    rs, zr = [None] * NV, [None] * NV
+    ok = True
+    for k in range(NV):
+        rt = np.zeros((64, 4), dtype)
+        for r in range(4):
+            yrow = bperm(y[k], 4 * G + r)
+            rt[:, r] = np.where(last_col, yrow, np.where(4 * G + r == Q, 1, 0))
+        row_tiles = [S[(k, k)]] + [S[(k, J)] for J in range(k + 1, NV)] + [rt]
+        dv = np.ones((64, 4), dtype)
+        for p in range(16):
+            gp, rp = p // 4, p % 4
+            a = row_tiles[0]
+            cola = bperm(a[:, rp], 16 * gp + irow)  # A[p][i], i = 4g + q%4
+            d = a[16 * gp + p, rp]
+            ok = ok and bool(d > 0)
+            inv = dtype(1) / d
+            m = np.where(irow > p, -cola * inv, dtype(0))
+            rows = [bperm(t[:, rp], 16 * gp + Q) for t in row_tiles]
+            for t in range(len(row_tiles)):
+                row_tiles[t] = mfma4(m, rows[t], row_tiles[t])
+            dv[:, rp] = np.where(G == gp, inv, dv[:, rp])
+        for j, J in enumerate(range(k + 1, NV)):
+            S[(k, J)] = row_tiles[1 + j]  # Z_J = inv(L) S_kJ
+        rt = row_tiles[-1]
+        zr[k] = np.stack([swizzle_lane15(rt[:, r]) for r in range(4)], axis=1)
+        dz = dv * zr[k]
+        rtrue = rt.copy()
+        for r in range(4):
+            rtrue[:, r] = np.where(last_col, np.where(4 * G + r == 15, 1, 0), rt[:, r])
+        rs[k] = dv * rtrue
+        for I in range(k + 1, NV):
+            zi = S[(k, I)]
+            for J in range(I, NV):
+                S[(I, J)] = mfma16(zi, -dv * S[(k, J)], S[(I, J)])
+            y[I] = y[I] - col_allreduce((zi * dz).sum(1))
+    xc = [None] * NV
+    for k in range(NV - 1, -1, -1):
+        w = np.zeros((64, 4), dtype)
+        for J in range(k + 1, NV):
+            w = w + S[(k, J)] * xc[J][:, None]
+        rhs = zr[k] - row_allreduce(w)
+        xc[k] = col_allreduce((rs[k] * rhs).sum(1))
+    return xc, ok
+
+
+def from_cols(xc, NV):
+    x = np.zeros(16 * NV, xc[0].dtype)
+    for k in range(NV):
+        x[np.arange(16) * NV + k] = xc[k][:16]
+    return x
+
+
 def to_tiles(A, b, NV):
     """dense (KP x KP) SPD matrix and rhs in natural order -> accumulator-layout tiles of the
     permuted matrix: tile (e,f)[t][t'] = A[t*NV+e][t'*NV+f], and column-layout rhs."""
@@ -163,14 +231,54 @@ def main():
                 xr, ok = block_solve(tiles, ycol, NV, dtype)
                 got = from_rows(xr, NV).astype(np.float64)
                 err = np.linalg.norm(got - want) / np.linalg.norm(want)
-                key = (NV, dtype.__name__)
+                key = (NV, dtype.__name__, 'inverse')
+                worst[key] = max(worst.get(key, 0.0), err)
+                assert ok
+                xc, ok = block_solve_ldl(tiles, ycol, NV, dtype)
+                got = from_cols(xc, NV).astype(np.float64)
+                err = np.linalg.norm(got - want) / np.linalg.norm(want)
+                key = (NV, dtype.__name__, 'ldl')
                 worst[key] = max(worst.get(key, 0.0), err)
                 assert ok
     for key in sorted(worst):
-        print('NV=%d %-8s worst relative error %.3e' % (key[0], key[1], worst[key]))
+        print('NV=%d %-8s %-8s worst relative error %.3e' % (key[0], key[1], key[2], worst[key]))
     bad = [k for k, v in worst.items() if v > (1e-11 if k[1] == 'float64' else 2e-4)]
     sys.exit(1 if bad else 0)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+def ill_conditioned():
+    """Rank-deficient Gram plus a small ridge (rows with fewer entries than dimensions and a
+    small alpha): block solve against a plain fp32 Cholesky solve, errors against fp64."""
+    rng = np.random.default_rng(7)
+    NV, KP, rank = 4, 64, 50
+    for n in (5, 20, 40, 80):
+        errs_b, errs_c, errs_l = [], [], []
+        for trial in range(5):
+            F = np.zeros((KP, n))
+            F[:rank] = rng.standard_normal((rank, n)) * 0.5 + 0.3
+            A = F.dot(F.T)
+            A[:rank, :rank] += 0.001 * n * np.eye(rank)
+            A[rank:, rank:] += np.eye(KP - rank)
+            b = F.dot(rng.integers(1, 6, n).astype(np.float64))
+            want = np.linalg.solve(A, b)
+            tiles, ycol = to_tiles(A.astype(np.float32), b.astype(np.float32), NV)
+            xr, ok = block_solve(tiles, ycol, NV, np.float32)
+            got = from_rows(xr, NV).astype(np.float64)
+            errs_b.append(np.linalg.norm(got - want) / np.linalg.norm(want))
+            xc_, ok = block_solve_ldl(tiles, ycol, NV, np.float32)
+            got = from_cols(xc_, NV).astype(np.float64)
+            errs_l.append(np.linalg.norm(got - want) / np.linalg.norm(want))
+            A32, b32 = A.astype(np.float32), b.astype(np.float32)
+            Lc = np.linalg.cholesky(A32)
+            xc = np.linalg.solve(Lc.T, np.linalg.solve(Lc, b32)).astype(np.float64)
+            errs_c.append(np.linalg.norm(xc - want) / np.linalg.norm(want))
+        print('n=%3d cond=%.1e  block inverse %.2e  block LDL %.2e  fp32 cholesky %.2e' %
+              (n, np.linalg.cond(A), max(errs_b), max(errs_l), max(errs_c)))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'ill':
+    ill_conditioned()
