@@ -306,6 +306,7 @@ __device__ __forceinline__ void gram_block32_split(Gram<float, NV> &G, ErrAcc<fl
 // (v_pk_mul_f32, v_cvt_pk_f16_f32 twice, two v_cvt_f32_f16, v_pk_add_f32 per pair) instead of
 // 5.5.  The accumulators hold S^2 * G; the ridge and the right-hand side are scaled to match
 // before the solve.  Operand map as for the bf16 instruction above.
+__device__ __forceinline__ float bperm(int byte_addr, float v);
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -326,11 +327,14 @@ __device__ __forceinline__ void gram_block32_f16(Gram<float, NV> &G, ErrAcc<floa
     constexpr int KP = NV * 16;
     float v[8][NV];
     float r[8];
+    // ds_bpermute byte address of lane 8g; the constant part of each neighbour's lane goes
+    // into the instruction's offset field, so one register serves all sixteen fetches
+    const int lane8g = 32 * g;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int t = 8 * g + j;
-        const unsigned id = (unsigned)__shfl(idx, off + t);
-        r[j] = __shfl(rv, off + t);
+        const unsigned id = (unsigned)__builtin_amdgcn_ds_bpermute(lane8g + 4 * (off + j), idx);
+        r[j] = bperm(lane8g + 4 * (off + j), rv);
         // uniform base + 32-bit byte offset (the host checks that the table is below 4 GiB)
         load_vec<float, NV>(v[j], reinterpret_cast<const float *>(
                                       reinterpret_cast<const char *>(src) + (id * (KP * 4u) + qoff)));
@@ -486,14 +490,28 @@ __device__ __forceinline__ void gram_accumulate(Gram<T, NV> &G, ErrAcc<T, NV, ER
 __global__ __launch_bounds__(256) void max_abs_kernel(const float *__restrict__ x, int64_t n4,
                                                       unsigned *__restrict__ out) {
     typedef float vec_t __attribute__((ext_vector_type(4)));
-    float m = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const vec_t t = reinterpret_cast<const vec_t *>(x)[i];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))));
+    __shared__ float part[4];
+    float m0 = 0.0f, m1 = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {  // two independent loads in flight
+        const vec_t a = reinterpret_cast<const vec_t *>(x)[i];
+        const vec_t b = reinterpret_cast<const vec_t *>(x)[i + stride];
+        m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+        m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))));
     }
+    if (i < n4) {
+        const vec_t a = reinterpret_cast<const vec_t *>(x)[i];
+        m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+    }
+    float m = fmaxf(m0, m1);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)  // one atomic per block
+        atomicMax(out, __builtin_bit_cast(
+                           unsigned, fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 
 // Waves per SIMD the fp32 rank-64 kernels are compiled for (register budget 512 / waves).
@@ -1300,7 +1318,7 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
             // scale of the fp16 split: the largest magnitude of the source table
             ALSMI_HIP_CHECK(hipMemsetAsync(pl->max_bits, 0, sizeof(unsigned), st));
             const int64_t n4 = n_src * (int64_t)(NV * 16) / 4;
-            int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 4 * (int64_t)pl->cu_count);
+            int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2 * (int64_t)pl->cu_count);
             if (blocks < 1) blocks = 1;
             hipLaunchKernelGGL(max_abs_kernel, dim3(blocks), dim3(256), 0, st,
                                static_cast<const float *>(src), n4, pl->max_bits);
