@@ -73,10 +73,9 @@ struct Gram {
 // equations the half-sweep builds anyway (src/als.py:161-165 computes the same quantity in a
 // separate pass over all entries):
 //     sum_t (r_t - <u, f_t>)^2 = sum_t r_t^2 - 2 <u, b> + u^T G u,   G = sum f f^T, b = sum r f.
-// Only sum r^2 has to be collected per entry (ErrAcc; ON = false compiles to nothing); the
-// two products are taken once per row from the accumulators (row_error_part).  Every rating is
-// seen by the 16 lanes of a group, so the per-lane sums count it 16 times; row_error_part
-// divides.
+// Only sum r^2 has to be collected per entry (ErrAcc; ON = false compiles to nothing): every
+// lane squares the one rating it loads per 64-entry block.  The two products are taken once
+// per row from the accumulators (row_error_part).
 template <typename T, int NV, bool ON>
 struct ErrAcc {
     T sum;
@@ -115,7 +114,7 @@ __device__ __forceinline__ double row_error_part(const Gram<T, NV> &G, T r2,
             quad += (e == f ? T(1) : T(2)) * t * uc[f];
         }
     }
-    return (double)r2 * 0.0625 - 2.0 * (double)ub + (double)(quad * inv_s2);
+    return (double)r2 - 2.0 * (double)ub + (double)(quad * inv_s2);
 }
 
 // One k=4 MFMA step: four neighbours (one per lane group), all upper tiles.
@@ -147,7 +146,6 @@ __device__ __forceinline__ void gram_steps(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        E.add(r[u]);
         gram_step<T, NV>(G, v[u], r[u]);
     }
 }
@@ -176,6 +174,7 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E
         const int cnt = left < WAVE ? (int)left : WAVE;
         const int idx = idx_n;
         const T rv = rv_n;
+        E.add(rv);  // lanes past the end hold a zero rating
         idx_n = 0;
         rv_n = T(0);
         if (base + WAVE + lane < end) {
@@ -202,7 +201,6 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E
             const bool valid = sl < cnt;
 #pragma unroll
             for (int e = 0; e < NV; ++e) v[e] = valid ? v[e] : T(0);
-            E.add(r1);
             gram_step<T, NV>(G, v, r1);
         }
     }
@@ -249,7 +247,6 @@ __device__ __forceinline__ void gram_block32_split(Gram<float, NV> &G, ErrAcc<fl
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        E.add(r[j]);
 #pragma unroll
         for (int e = 0; e < NV; ++e) G.b[e] += r[j] * v[j][e];
     }
@@ -346,7 +343,6 @@ __device__ __forceinline__ void gram_block32_f16(Gram<float, NV> &G, ErrAcc<floa
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        E.add(r[j]);
 #pragma unroll
         for (int e = 0; e < NV; ++e) G.b[e] += r[j] * v[j][e];
     }
@@ -445,6 +441,7 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
         const int cnt = left < WAVE ? (int)left : WAVE;
         const int idx = idx_n;
         const float rv = rv_n;
+        E.add(rv);  // lanes past the end hold a zero rating
         idx_n = 0;
         rv_n = 0.0f;
         if (base + WAVE + lane < end) {
@@ -1099,7 +1096,9 @@ struct SolveArgs {
 template <typename T, int KP, bool DUMP>
 struct WaveLds {
     static constexpr bool FAST = !DUMP && KP <= 64;
-    static constexpr int ELEMS = FAST ? Stage<T, KP < 64 ? KP : 64>::ELEMS : Slab<T, KP>::ELEMS;
+    static constexpr int WORK = FAST ? Stage<T, KP < 64 ? KP : 64>::ELEMS : Slab<T, KP>::ELEMS;
+    // + 64 doubles behind the work area: the lanes' squared-error partial sums
+    static constexpr int ELEMS = (WORK + 1) / 2 * 2 + 512 / (int)sizeof(T);
     static constexpr size_t BYTES = (size_t)ELEMS * sizeof(T);
 };
 
@@ -1129,7 +1128,11 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
     float scale = 1.0f;
     if constexpr (MODE == GRAM_F16X2) scale = split_scale(p.max_bits[0]);
     const T s2 = (T)(scale * scale), inv_s2 = (T)(1.0f / (scale * scale));
-    double lane_err = 0.0;  // this lane's share of the squared error of the wave's rows
+    // This lane's share of the squared error of the wave's rows lives in the wave's LDS area
+    // (64 doubles behind the work area), not in two registers across the gather.
+    double *lane_err_slot =
+        reinterpret_cast<double *>(Asm + (WaveLds<T, KP, DUMP>::WORK + 1) / 2 * 2) + lane;
+    if constexpr (ERR) *lane_err_slot = 0.0;
     for (int t = blockIdx.x * WPB + wl; t < p.n_tasks; t += W) {
         const int row = p.order[t];
         const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
@@ -1169,7 +1172,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
         if constexpr (ERR) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            lane_err += row_error_part<T, NV>(G, E.sum, Asm, lane, inv_s2);
+            *lane_err_slot += row_error_part<T, NV>(G, E.sum, Asm, lane, inv_s2);
         }
         if constexpr (MODE == GRAM_F16X2) {  // (S^2 A) x = S^2 b
 #pragma unroll
@@ -1220,7 +1223,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
         __builtin_amdgcn_wave_barrier();
     }
     if constexpr (ERR) {
-        const double wave_err = wave_sum(lane_err);
+        const double wave_err = wave_sum(*lane_err_slot);
         if (lane == 0) p.err_part[blockIdx.x * WPB + wl] = wave_err;
     }
 }
