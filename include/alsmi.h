@@ -77,7 +77,13 @@ int alsmi_plan_info(const alsmi_plan *plan, int64_t *n_rows, int64_t *n_heavy_ro
  * with f_t = src_factors[indices[t]] over the row's n_r stored entries
  * (src/als.py:243-247); an empty row or a matrix that is not positive definite
  * gives a zero vector (the reference's LinAlgError branch, src/als.py:248-249).
- * Rows outside the plan's range are not touched. */
+ * Rows outside the plan's range are not touched.
+ * ALSMI_F32 with rank <= 64: the products f f^T are formed on the fp16 matrix cores
+ * from values scaled by a power of two taken from the largest |element| of the
+ * source table (read once per call); the result has fp32 accuracy for
+ * 2^-40 <= max|src| <= 2^40 and a source table of at most 4 GiB, elements below
+ * max|src| * 2^-16 lose precision relative to themselves only.  Results are
+ * bit-reproducible from run to run. */
 int alsmi_half_sweep(alsmi_plan *plan, const int64_t *indptr, const int32_t *indices,
                      const void *vals, const void *src_factors, int64_t n_src,
                      void *dst_factors, double alpha, void *stream);

@@ -150,6 +150,46 @@ def test_half_sweep_is_reproducible(gpu, dtype, rank):
     plan.close()
 
 
+@pytest.mark.parametrize('scale', [1e-9, 1e-4, 1.0, 3e3, 1e7])
+def test_fp32_half_sweep_any_factor_magnitude(gpu, scale):
+    """The fp32 Gram build splits scaled values into fp16 pairs; the scale follows the largest
+    magnitude of the source table, so tiny and huge factors keep fp32-level accuracy (the ridge
+    is scaled along so that the conditioning is that of the unit-scale problem)."""
+    device, torch = gpu
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    rank = 64
+    P = random_problem(31, 300, 400, 20000, rank)
+    Vs = P['V'] * scale
+    Vs[:, 7] *= 1e-5      # one row far below the rest
+    Vs[3, :] *= 1e-3      # one dimension far below the rest
+    alpha = 0.1 * scale * scale
+    side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], 300, 400, 'float32', device)
+    plan = dev.SweepPlan(side, rank)
+    V = dev.factors_to_device(Vs, 'float32', device)
+    U = V.new_zeros((300, dev.padded_rank(rank)))
+    plan.half_sweep(V, U, alpha)
+    got = dev.factors_to_host(U, rank)
+    want = ao.half_sweep(P['indptr'], P['indices'], P['vals'], dev.factors_to_host(V, rank), rank,
+                         alpha)
+    assert col_rel_err(got, want) < 1e-4
+    plan.close()
+
+
+def test_fp32_half_sweep_zero_source_table(gpu):
+    """An all-zero source table (largest magnitude 0) with a positive ridge: zero solution."""
+    device, torch = gpu
+    from alsmi import device as dev
+    P = random_problem(32, 50, 60, 900, 64)
+    side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], 50, 60, 'float32', device)
+    plan = dev.SweepPlan(side, 64)
+    V = torch.zeros((60, 64), dtype=torch.float32, device=device)
+    U = torch.ones((50, 64), dtype=torch.float32, device=device)
+    plan.half_sweep(V, U, 0.1)
+    assert not U.cpu().numpy().any()
+    plan.close()
+
+
 def test_half_sweep_singular_gives_zeros(gpu):
     """A = 0 (zero source factors, alpha = 0): the reference's inv() raises
     LinAlgError and the row becomes zeros (src/als.py:246-249)."""

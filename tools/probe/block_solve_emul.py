@@ -123,7 +123,7 @@ def block_solve(tiles, ycol, NV, dtype=np.float32):
 
 
 def swizzle_lane15(v):
-    """ds_swizzle, bit mode, and 0x10 or 0x0F: every lane reads lane 15 of its row."""
+    """every lane reads lane 15 of its row (a ds_bpermute with address 4*(16g+15) in the kernel)."""
     return v[(LANES & 0x30) | 15]
 
 
