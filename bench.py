@@ -33,6 +33,9 @@ CONFIGS = {
     # name: users per GPU, items, stored entries per GPU, rank
     'c2': dict(n=138493, m=26744, nnz=20000000, rank=64,
                workload='ALS rank 64, synthetic ML-20M shape 138493x26744, 20M nnz per GPU'),
+    'r128': dict(n=138493, m=26744, nnz=20000000, rank=128,
+                 workload='ALS rank 128, synthetic ML-20M shape 138493x26744, 20M nnz per GPU '
+                          '(single-GPU slice of the rank-128 configuration)'),
     'small': dict(n=20000, m=5000, nnz=1000000, rank=64,
                   workload='ALS rank 64, synthetic 20000x5000, 1M nnz per GPU (smoke size)'),
 }

@@ -459,15 +459,16 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
     }
 }
 
-// fp32 data up to padded rank 64 goes to the 16-bit matrix cores; fp64 keeps its own MFMA, and
-// so does fp32 at padded rank 128, where the operand sets next to 36 accumulator tiles no
-// longer fit the register file.  The debug dump of the normal equations wants unscaled
-// accumulators and takes the bf16 split.  ABLATE 4 / 10 force the native MFMA / the bf16 split
+// fp32 data goes to the 16-bit matrix cores (at padded rank 128 with one wave per SIMD: 36
+// accumulator tiles in the accumulation registers, the operand sets in the others); fp64 keeps
+// its own MFMA.  The debug dump of the normal equations wants unscaled accumulators and takes
+// the bf16 split up to padded rank 64, the native MFMA above.  ABLATE 4 / 10 force the native MFMA / the bf16 split
 // (timing comparisons).
 template <typename T, int NV, int ABLATE, bool DUMP>
 constexpr int gram_mode() {
-    if (sizeof(T) != 4 || NV > 4 || ABLATE == 4) return GRAM_NATIVE;
-    return (DUMP || ABLATE == 10) ? GRAM_BF16X3 : GRAM_F16X2;
+    if (sizeof(T) != 4 || NV > 8 || ABLATE == 4) return GRAM_NATIVE;
+    if (DUMP) return NV <= 4 ? GRAM_BF16X3 : GRAM_NATIVE;
+    return ABLATE == 10 ? GRAM_BF16X3 : GRAM_F16X2;
 }
 
 template <typename T, int NV, int MODE, bool ERR>
@@ -900,58 +901,48 @@ __device__ __forceinline__ f4 mfma_xty(f4 x, f4 y, f4 c) {
     return c;
 }
 
-// Solves the NV*16 system held in G (ridge not yet added).  xc[k] of lane (.,q) is the solution
-// component of dimension q*NV + k.  Returns false when a pivot is not positive or the result is
-// not finite.
-template <int NV>
-__device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int rank, float ridge,
-                                            float (&xc)[NV]) {
-    // The lane-dependent constants below are cheap to derive; hiding the lane id from the
-    // optimiser keeps them from being hoisted out of the row loop, where they would occupy
-    // registers (or spill slots) throughout the accumulation.
-    asm volatile("" : "+v"(lane));
-    const int g = lane >> 4, q = lane & 15;
-    const int irow = 4 * g + (q & 3);  // the tile row this lane feeds to the 4x4x1 instruction
-    const int addr_row = 4 * q;        // + 64*gp: lane (gp, q)
-    const int addr_col = 4 * irow;     // + 64*gp: lane (gp, irow)
-    add_ridge<float, NV>(G, lane, rank, ridge);
-    float y[NV];
-#pragma unroll
-    for (int e = 0; e < NV; ++e) y[e] = col_allreduce(G.b[e]);
-    // Per pivot block, kept for the back substitution: D^-1 inv(L_kk) (rows scaled) and
-    // z_k = inv(L_kk) y_k in the row layout.
-    f4 rs[NV], zr[NV];
-    int bad = 0;
-    const bool last_col = q == 15;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
+// Lane constants of the block solver.
+struct SolveLane {
+    int g, q, irow, addr_row, addr_col;
+    bool last_col;
+};
+
+// Forward phase of pivot block K (see above); K is a template parameter so that every tile
+// index is static — a loop over K that the optimiser declines to unroll would turn the
+// accumulators into scratch memory.
+template <int NV, int K>
+struct PivotBlock {
+    static __device__ __forceinline__ void run(Gram<float, NV> &G, const SolveLane &L,
+                                               float (&y)[NV], f4 (&rs)[NV], f4 (&zr)[NV],
+                                               int &bad) {
+        const int g = L.g, q = L.q;
         // R starts as the identity.  Its last column stays e_15 whatever the row operations, so
         // it carries the right-hand side instead: the same operations turn y into inv(L) y.
         f4 rt, dv = {1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float yrow = bperm(4 * (4 * g + r), y[k]);  // column -> row layout
-            rt[r] = last_col ? yrow : ((4 * g + r == q) ? 1.0f : 0.0f);
+            const float yrow = bperm(4 * (4 * g + r), y[K]);  // column -> row layout
+            rt[r] = L.last_col ? yrow : ((4 * g + r == q) ? 1.0f : 0.0f);
         }
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int gp = p >> 2, rp = p & 3;
-            f4 &a = G.acc[tri_index(k, k, NV)];
+            f4 &a = G.acc[tri_index(K, K, NV)];
             const float src = a[rp];
-            const float cola = bperm(addr_col + 64 * gp, src);  // A[p][irow] = A[irow][p]
+            const float cola = bperm(L.addr_col + 64 * gp, src);  // A[p][irow] = A[irow][p]
             const float d = read_lane(src, 16 * gp + p);
             const float inv = __builtin_amdgcn_rcpf(d);  // 1 ulp; a multiplier needs no more
-            const float m = (irow > p) ? -cola * inv : 0.0f;
+            const float m = (L.irow > p) ? -cola * inv : 0.0f;
             // all row fetches of the step first, so that their latencies overlap
             float rows[NV + 1];
 #pragma unroll
-            for (int j = k; j < NV; ++j)
-                rows[j] = bperm(addr_row + 64 * gp, G.acc[tri_index(k, j, NV)][rp]);
-            rows[NV] = bperm(addr_row + 64 * gp, rt[rp]);
+            for (int j = K; j < NV; ++j)
+                rows[j] = bperm(L.addr_row + 64 * gp, G.acc[tri_index(K, j, NV)][rp]);
+            rows[NV] = bperm(L.addr_row + 64 * gp, rt[rp]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = k; j < NV; ++j) {
-                f4 &t = G.acc[tri_index(k, j, NV)];
+            for (int j = K; j < NV; ++j) {
+                f4 &t = G.acc[tri_index(K, j, NV)];
                 t = __builtin_amdgcn_mfma_f32_4x4x1f32(m, rows[j], t, 0, 0, 0);
             }
             rt = __builtin_amdgcn_mfma_f32_4x4x1f32(m, rows[NV], rt, 0, 0, 0);
@@ -964,44 +955,82 @@ __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int ra
         f4 dz;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            zr[k][r] = bperm(4 * (16 * g + 15), rt[r]);  // z from lane 15 of each row
-            dz[r] = dv[r] * zr[k][r];
-            const float rtrue = last_col ? ((4 * g + r == 15) ? 1.0f : 0.0f) : rt[r];
-            rs[k][r] = dv[r] * rtrue;
+            zr[K][r] = bperm(4 * (16 * g + 15), rt[r]);  // z from lane 15 of each row
+            dz[r] = dv[r] * zr[K][r];
+            const float rtrue = L.last_col ? ((4 * g + r == 15) ? 1.0f : 0.0f) : rt[r];
+            rs[K][r] = dv[r] * rtrue;
         }
-        f4 nz[NV];
 #pragma unroll
-        for (int j = k + 1; j < NV; ++j) nz[j] = -dv * G.acc[tri_index(k, j, NV)];
-#pragma unroll
-        for (int i = k + 1; i < NV; ++i) {
-            const f4 zi = G.acc[tri_index(k, i, NV)];
+        for (int i = K + 1; i < NV; ++i) {
+            const f4 zi = G.acc[tri_index(K, i, NV)];
 #pragma unroll
             for (int j = i; j < NV; ++j)
-                G.acc[tri_index(i, j, NV)] = mfma_xty(zi, nz[j], G.acc[tri_index(i, j, NV)]);
+                G.acc[tri_index(i, j, NV)] = mfma_xty(zi, -dv * G.acc[tri_index(K, j, NV)],
+                                                      G.acc[tri_index(i, j, NV)]);
             float part = 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
             y[i] -= col_allreduce(part);
         }
+        PivotBlock<NV, K + 1>::run(G, L, y, rs, zr, bad);
     }
-    // x_k = inv(L_kk)^T D^-1 (z_k - sum_J Z_kJ x_J)
-    float chk = 0.0f;
-#pragma unroll
-    for (int k = NV - 1; k >= 0; --k) {
-        f4 rhs = zr[k];
-        if (k < NV - 1) {
+};
+template <int NV>
+struct PivotBlock<NV, NV> {
+    static __device__ __forceinline__ void run(Gram<float, NV> &, const SolveLane &, float (&)[NV],
+                                               f4 (&)[NV], f4 (&)[NV], int &) {}
+};
+
+// Back substitution of block K: x_K = inv(L_KK)^T D^-1 (z_K - sum_J Z_KJ x_J), last block first.
+template <int NV, int K>
+struct BackBlock {
+    static __device__ __forceinline__ void run(const Gram<float, NV> &G, const f4 (&rs)[NV],
+                                               const f4 (&zr)[NV], float (&xc)[NV], float &chk) {
+        f4 rhs = zr[K];
+        if constexpr (K < NV - 1) {
             f4 w = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int j = k + 1; j < NV; ++j) w += G.acc[tri_index(k, j, NV)] * xc[j];
+            for (int j = K + 1; j < NV; ++j) w += G.acc[tri_index(K, j, NV)] * xc[j];
 #pragma unroll
             for (int r = 0; r < 4; ++r) rhs[r] -= row_allreduce(w[r]);
         }
         float part = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part += rs[k][r] * rhs[r];
-        xc[k] = col_allreduce(part);
-        chk += fabsf(xc[k]);
+        for (int r = 0; r < 4; ++r) part += rs[K][r] * rhs[r];
+        xc[K] = col_allreduce(part);
+        chk += fabsf(xc[K]);
+        if constexpr (K > 0) BackBlock<NV, K - 1>::run(G, rs, zr, xc, chk);
     }
+};
+
+// Solves the NV*16 system held in G (ridge not yet added).  xc[k] of lane (.,q) is the solution
+// component of dimension q*NV + k.  Returns false when a pivot is not positive or the result is
+// not finite.
+template <int NV>
+__device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int rank, float ridge,
+                                            float (&xc)[NV]) {
+    // The lane-dependent constants below are cheap to derive; hiding the lane id from the
+    // optimiser keeps them from being hoisted out of the row loop, where they would occupy
+    // registers (or spill slots) throughout the accumulation.
+    asm volatile("" : "+v"(lane));
+    SolveLane L;
+    L.g = lane >> 4;
+    L.q = lane & 15;
+    L.irow = 4 * L.g + (L.q & 3);  // the tile row this lane feeds to the 4x4x1 instruction
+    L.addr_row = 4 * L.q;          // + 64*gp: lane (gp, q)
+    L.addr_col = 4 * L.irow;       // + 64*gp: lane (gp, irow)
+    L.last_col = L.q == 15;
+    add_ridge<float, NV>(G, lane, rank, ridge);
+    float y[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) y[e] = col_allreduce(G.b[e]);
+    // Per pivot block, kept for the back substitution: D^-1 inv(L_kk) (rows scaled) and
+    // z_k = inv(L_kk) y_k in the row layout.
+    f4 rs[NV], zr[NV];
+    int bad = 0;
+    PivotBlock<NV, 0>::run(G, L, y, rs, zr, bad);
+    float chk = 0.0f;
+    BackBlock<NV, NV - 1>::run(G, rs, zr, xc, chk);
     return !__any(bad != 0 || !(chk < INFINITY));
 }
 
@@ -1095,7 +1124,7 @@ struct SolveArgs {
 // <= 64, no dump), the whole matrix otherwise.
 template <typename T, int KP, bool DUMP>
 struct WaveLds {
-    static constexpr bool FAST = !DUMP && KP <= 64;
+    static constexpr bool FAST = !DUMP && (KP <= 64 || (sizeof(T) == 4 && KP <= 128));
     static constexpr int WORK = FAST ? Stage<T, KP < 64 ? KP : 64>::ELEMS : Slab<T, KP>::ELEMS;
     // + 64 doubles behind the work area: the lanes' squared-error partial sums
     static constexpr int ELEMS = (WORK + 1) / 2 * 2 + 512 / (int)sizeof(T);
@@ -1308,8 +1337,8 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
                           double *err_out, hipStream_t st) {
     const bool dump = A_out != nullptr;
     int mode = GRAM_NATIVE;
-    if constexpr (sizeof(T) == 4 && NV <= 4) {
-        mode = dump ? GRAM_BF16X3 : GRAM_F16X2;
+    if constexpr (sizeof(T) == 4 && NV <= 8) {
+        mode = dump ? (NV <= 4 ? GRAM_BF16X3 : GRAM_NATIVE) : GRAM_F16X2;
         if constexpr (NV == 4) {
             if (!dump && !err_out && ablation() == 4) mode = GRAM_NATIVE;
             if (!dump && !err_out && ablation() == 10) mode = GRAM_BF16X3;
@@ -1332,11 +1361,12 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
         const int grid = (pl->n_chunks + 3) / 4;
         auto chunks = gram_chunks_kernel<T, NV, GRAM_NATIVE, false>;
         if (err_out) chunks = gram_chunks_kernel<T, NV, GRAM_NATIVE, true>;
-        if constexpr (sizeof(T) == 4 && NV <= 4) {
+        if constexpr (sizeof(T) == 4 && NV <= 8) {
             if (mode == GRAM_F16X2)
                 chunks = err_out ? gram_chunks_kernel<T, NV, GRAM_F16X2, true>
                                  : gram_chunks_kernel<T, NV, GRAM_F16X2, false>;
-            if (mode == GRAM_BF16X3) chunks = gram_chunks_kernel<T, NV, GRAM_BF16X3, false>;
+            if constexpr (NV <= 4)
+                if (mode == GRAM_BF16X3) chunks = gram_chunks_kernel<T, NV, GRAM_BF16X3, false>;
         }
         hipLaunchKernelGGL(chunks, dim3(grid), dim3(256), 0, st, pl->ch_beg, pl->ch_end,
                            pl->n_chunks, indices, static_cast<const T *>(vals),

@@ -125,7 +125,8 @@ def test_half_sweep_with_error_of_replaced_factors(gpu, case, dtype):
     plan.close()
 
 
-@pytest.mark.parametrize('dtype,rank', [('float32', 64), ('float32', 20), ('float64', 64)])
+@pytest.mark.parametrize('dtype,rank', [('float32', 64), ('float32', 20), ('float32', 128),
+                                        ('float64', 64)])
 def test_half_sweep_is_reproducible(gpu, dtype, rank):
     """The same half-sweep run three times gives bit-identical factors and error sums (fixed
     summation order, no timing-dependent path), with long rows cut into chunks included."""

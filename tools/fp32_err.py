@@ -16,7 +16,8 @@ from oracle import c_oracle as co  # noqa: E402
 
 device = dev.require_gpu()
 CASES = [(11, 300, 200, 6000, 10, 0), (12, 400, 300, 30000, 32, 0), (13, 2000, 1500, 150000, 64, 0),
-         (14, 500, 3000, 200000, 64, 256), (15, 3000, 800, 60000, 50, 0)]
+         (14, 500, 3000, 200000, 64, 256), (15, 3000, 800, 60000, 50, 0),
+         (16, 1500, 1200, 150000, 128, 0), (17, 600, 2500, 200000, 100, 256)]
 for seed, n, m, nnz, rank, chunk in CASES:
     P = random_problem(seed, n, m, nnz, rank)
     for alpha in (0.1, 0.001):
