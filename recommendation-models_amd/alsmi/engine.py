@@ -35,8 +35,8 @@ class LocalBackend(object):
     def make_side(self, indptr, indices, vals, n_rows, n_cols, dtype):
         return dev.SparseSide(indptr, indices, vals, n_rows, n_cols, dtype, self.device)
 
-    def make_plan(self, side, rank, chunk):
-        return dev.SweepPlan(side, rank, chunk=chunk)
+    def make_plan(self, side, rank, chunk, row_begin=0, row_end=None):
+        return dev.SweepPlan(side, rank, row_begin=row_begin, row_end=row_end, chunk=chunk)
 
     def zeros(self, rows, cols, dtype):
         return torch.zeros((rows, cols), dtype=dev.torch_dtype(dtype), device=self.device)
@@ -63,7 +63,8 @@ class AlsEngine(object):
     rank's row range (world+1 entries each); None means a single rank."""
 
     def __init__(self, csr, csc, shape, rank, alpha, dtype=np.float64, user_bounds=None,
-                 item_bounds=None, group=None, backend=None, chunk=0, total_nnz=None):
+                 item_bounds=None, group=None, backend=None, chunk=0, total_nnz=None,
+                 user_slabs=None):
         self.backend = backend if backend is not None else LocalBackend()
         self.n, self.m = int(shape[0]), int(shape[1])
         self.rank, self.alpha = int(rank), float(alpha)
@@ -86,7 +87,14 @@ class AlsEngine(object):
         b = self.backend
         self.csr = b.make_side(csr[0], csr[1], csr[2], self.uhi - self.ulo, self.m, self.dtype)
         self.csc = b.make_side(csc[0], csc[1], csc[2], self.ihi - self.ilo, self.n, self.dtype)
-        self.plan_u = b.make_plan(self.csr, self.rank, chunk)
+        # The user table is the large one (its all-gather is what a multi-rank sweep waits
+        # for), so with several ranks the user half runs as a few row slabs, balanced by
+        # entries, and the gather of one slab travels while the next is computed.
+        if user_slabs is None:
+            user_slabs = 1 if self.world == 1 else 4
+        self.u_sub = split_by_nnz(self.csr.indptr_host, max(1, int(user_slabs)))
+        self.plans_u = [b.make_plan(self.csr, self.rank, chunk, int(lo), int(hi))
+                        for lo, hi in zip(self.u_sub[:-1], self.u_sub[1:])]
         self.plan_i = b.make_plan(self.csc, self.rank, chunk)
         self.kp = b.padded_rank(self.rank)
         self.U = b.zeros(self.n, self.kp, self.dtype)
@@ -103,10 +111,19 @@ class AlsEngine(object):
                 dist.all_reduce(t, group=group)
                 total_nnz = int(t.cpu()[0])
         self.nnz = int(total_nnz)
+        # every rank's slab boundaries (global row ids), [world x slabs+1]
+        mine = torch.from_numpy(self.u_sub + self.ulo).to(self.U.device)
+        if self.world > 1:
+            import torch.distributed as dist
+            every = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(every, mine, group=group)
+            self.u_sub_all = every.cpu().numpy().reshape(self.world, -1)
+        else:
+            self.u_sub_all = mine.cpu().numpy().reshape(1, -1)
 
     @classmethod
     def from_global(cls, indptr, indices, vals, shape, rank, alpha, dtype=np.float64,
-                    group=None, backend=None, chunk=0):
+                    group=None, backend=None, chunk=0, user_slabs=None):
         """Every rank is given the whole CSR (host arrays or device tensors).  The CSC is
         built on the device (the reference re-runs scipy's csr_tocsc per item,
         src/als.py:268-280), both are cut into per-rank row ranges balanced by stored
@@ -128,7 +145,8 @@ class AlsEngine(object):
         a, z = int(cptr_h[ib[me]]), int(cptr_h[ib[me + 1]])
         csc = (cptr_h[ib[me]:ib[me + 1] + 1] - a, cidx[a:z], cval[a:z])
         return cls(csr, csc, (n, m), rank, alpha, dtype=dtype, user_bounds=ub, item_bounds=ib,
-                   group=group, backend=backend, chunk=chunk, total_nnz=int(ptr_h[-1]))
+                   group=group, backend=backend, chunk=chunk, total_nnz=int(ptr_h[-1]),
+                   user_slabs=user_slabs)
 
     # ---- factors ------------------------------------------------------------
     def set_factors(self, user_feats, item_feats):
@@ -165,10 +183,51 @@ class AlsEngine(object):
                 table[int(bounds[r]):int(bounds[r + 1])].copy_(
                     recv[r * width:r * width + int(sizes[r])])
 
+    def _start_slab_gather(self, table, s):
+        """Begin the all-gather of user slab s (rows u_sub_all[r, s:s+2] of every rank r) and
+        return what `_finish_slab_gather` needs.  The collective is ordered after the kernels
+        already enqueued on the current stream and runs beside the ones enqueued later."""
+        import torch.distributed as dist
+        lo = self.u_sub_all[:, s]
+        sizes = self.u_sub_all[:, s + 1] - lo
+        width = int(sizes.max())
+        send = torch.zeros((width, table.shape[1]), dtype=table.dtype, device=table.device)
+        mlo = int(lo[self.me])
+        send[:int(sizes[self.me])].copy_(table[mlo:mlo + int(sizes[self.me])])
+        recv = torch.empty((self.world * width, table.shape[1]), dtype=table.dtype,
+                           device=table.device)
+        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        return work, recv, send, lo, sizes, width
+
+    def _finish_slab_gather(self, table, pending):
+        work, recv, _send, lo, sizes, width = pending
+        work.wait()
+        for r in range(self.world):
+            if r != self.me and sizes[r]:
+                table[int(lo[r]):int(lo[r] + sizes[r])].copy_(
+                    recv[r * width:r * width + int(sizes[r])])
+
     # ---- the loop body ------------------------------------------------------
+    def _user_half(self, cur, dst, table, want_err):
+        """Solve every slab of this rank's users into `dst` (local rows); when `table` is
+        given, gather each finished slab into it while the next one is computed.  Returns
+        the squared error of `cur` (local part, device tensor) or None."""
+        sse = None
+        pending = []
+        for s, plan in enumerate(self.plans_u):
+            if want_err:
+                part = plan.half_sweep_err(self.V, cur, dst, self.alpha)
+                sse = part if sse is None else sse + part
+            else:
+                plan.half_sweep(self.V, dst, self.alpha)
+            if table is not None and self.world > 1:
+                pending.append(self._start_slab_gather(table, s))
+        for p in pending:
+            self._finish_slab_gather(table, p)
+        return sse
+
     def half_sweep_users(self):
-        self.plan_u.half_sweep(self.V, self.U[self.ulo:self.uhi], self.alpha)
-        self._all_gather_rows(self.U, self.user_bounds)
+        self._user_half(None, self.U[self.ulo:self.uhi], self.U, False)
 
     def half_sweep_users_err(self, keep_old=False):
         """The user half-sweep, which also gives the squared training error of the
@@ -181,17 +240,13 @@ class AlsEngine(object):
         if keep_old:
             if self._U_next is None:
                 self._U_next = torch.zeros_like(mine)
-            dst = self._U_next
+            sse = self._user_half(mine, self._U_next, None, True)
+            self._pending = True
         else:
-            dst = mine
-        sse = self.plan_u.half_sweep_err(self.V, mine, dst, self.alpha)
+            sse = self._user_half(mine, mine, self.U, True)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(sse, group=self.group)
-        if keep_old:
-            self._pending = True
-        else:
-            self._all_gather_rows(self.U, self.user_bounds)
         return sse
 
     def commit_users(self):

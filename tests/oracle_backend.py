@@ -27,27 +27,32 @@ class OracleSide(object):
 
 
 class OraclePlan(object):
-    def __init__(self, side, rank):
+    def __init__(self, side, rank, row_begin=0, row_end=None):
         self.side, self.rank = side, rank
+        self.row_begin = int(row_begin)
+        self.row_end = side.n_rows if row_end is None else int(row_end)
 
     def half_sweep(self, src, dst, alpha):
         s = self.side
-        if s.n_rows == 0:
+        if self.row_end <= self.row_begin:
             return
         out = co.half_sweep(s.indptr_host, s.indices_np, s.vals_np,
-                            src[:, :self.rank].numpy(), alpha, threads=1)
-        dst[:s.n_rows, :self.rank] = torch.from_numpy(out)
+                            src[:, :self.rank].numpy(), alpha, row_begin=self.row_begin,
+                            row_end=self.row_end, threads=1)
+        dst[self.row_begin:self.row_end, :self.rank] = torch.from_numpy(out)
 
 
     def half_sweep_err(self, src, cur, dst, alpha):
         s = self.side
         sse = torch.zeros(1, dtype=torch.float64)
-        if s.n_rows == 0:
+        if self.row_end <= self.row_begin:
             return sse
-        rows = np.repeat(np.arange(s.n_rows), np.diff(s.indptr_host))
+        a, z = int(s.indptr_host[self.row_begin]), int(s.indptr_host[self.row_end])
+        rows = np.repeat(np.arange(self.row_begin, self.row_end),
+                         np.diff(s.indptr_host[self.row_begin:self.row_end + 1]))
         pred = (cur[:s.n_rows, :self.rank].numpy()[rows] *
-                src[:, :self.rank].numpy()[s.indices_np]).sum(-1)
-        sse[0] = float(((s.vals_np - pred) ** 2).sum())
+                src[:, :self.rank].numpy()[s.indices_np[a:z]]).sum(-1)
+        sse[0] = float(((s.vals_np[a:z] - pred) ** 2).sum())
         self.half_sweep(src, dst, alpha)
         return sse
 
@@ -56,8 +61,8 @@ class OracleBackend(object):
     def make_side(self, indptr, indices, vals, n_rows, n_cols, dtype):
         return OracleSide(indptr, indices, vals, n_rows, n_cols, dtype)
 
-    def make_plan(self, side, rank, chunk):
-        return OraclePlan(side, rank)
+    def make_plan(self, side, rank, chunk, row_begin=0, row_end=None):
+        return OraclePlan(side, rank, row_begin, row_end)
 
     def zeros(self, rows, cols, dtype):
         return torch.zeros((rows, cols), dtype=torch.float64)

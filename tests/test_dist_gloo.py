@@ -71,6 +71,13 @@ def worker(rank_id, world, port, case, out_dir):
         eng.discard_users()
         assert abs(again - hist[1]) <= 1e-10 * abs(hist[1])
         assert torch.equal(eng.U, before)
+        # third sweep in place (the schedule of bench.py and of ALS.fit(max_iter=...)): the
+        # user half runs slab by slab with the slabs' all-gathers in flight beside it
+        assert len(eng.plans_u) == 4
+        inplace = float(eng.half_sweep_users_err()[0])
+        assert abs(inplace - hist[1]) <= 1e-10 * abs(hist[1])
+        eng.half_sweep_items()
+        hist.append(float(eng.train_sse_async()[0]))
         uf, itf = eng.get_factors()
         np.savez(os.path.join(out_dir, 'rank%d.npz' % rank_id), uf=uf, itf=itf, hist=hist,
                  ub=eng.user_bounds, ib=eng.item_bounds)
@@ -92,7 +99,7 @@ def test_sharded_sweeps_match_single_process(tmp_path, world, case):
     mp.spawn(worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
     seed, n, m, nnz, rank, extra = case
     P = random_problem(seed, n, m, nnz, rank, **extra)
-    uf, itf, hist = reference_run(P, rank, 0.1, 2)
+    uf, itf, hist = reference_run(P, rank, 0.1, 3)
     outs = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(world)]
     for o in outs:
         # every rank ends with the full, identical factor tables

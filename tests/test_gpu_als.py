@@ -191,6 +191,26 @@ def test_fp32_half_sweep_zero_source_table(gpu):
     plan.close()
 
 
+def test_user_slabs_change_nothing(gpu):
+    """The engine may cut the user half into row slabs (to overlap their all-gathers with the
+    computation on several ranks); a row's result does not depend on the cut."""
+    device, torch = gpu
+    from alsmi.engine import AlsEngine
+    P = random_problem(41, 500, 300, 20000, 20, long_row=(9, 280))
+    res = []
+    for slabs in (1, 3):
+        eng = AlsEngine.from_global(P['indptr'], P['indices'], P['vals'], (500, 300), 20, 0.1,
+                                    dtype='float32', user_slabs=slabs, chunk=64)
+        assert len(eng.plans_u) == slabs
+        eng.set_factors(np.zeros_like(P['U']), P['V'])
+        eng.sweep()
+        sse = float(eng.half_sweep_users_err().cpu()[0])
+        eng.half_sweep_items()
+        res.append((eng.U.clone(), eng.V.clone(), sse))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert abs(res[0][2] - res[1][2]) <= 1e-12 * res[0][2]
+
+
 def test_half_sweep_singular_gives_zeros(gpu):
     """A = 0 (zero source factors, alpha = 0): the reference's inv() raises
     LinAlgError and the row becomes zeros (src/als.py:246-249)."""

@@ -57,7 +57,7 @@ def test_sampled_rows_match_oracle_at_full_size(problem, dtype, tol):
     from oracle import c_oracle as co
     torch, P = problem['torch'], problem['prob']
     eng = problem['AlsEngine'](P['csr'], P['csc'], P['shape'], RANK, 0.1, dtype=dtype)
-    assert eng.plan_u.info()['n_chunks'] > 0 and eng.plan_i.info()['n_chunks'] > 1000
+    assert eng.plans_u[0].info()['n_chunks'] > 0 and eng.plan_i.info()['n_chunks'] > 1000
     eng.set_factors(np.zeros((RANK, N_USERS)), problem['V0'])
     Vq = eng.V[:, :RANK].to(torch.float64).cpu().numpy()
 
