@@ -214,7 +214,7 @@ def main():
                 traffic = None
         sweeps_per_sec = args.steps / elapsed
         line = {
-            'metric': 'ALS nnz/sec (stored entries x sweeps/sec), ML-20M shape rank 64',
+            'metric': 'ALS nnz/sec (stored entries x sweeps/sec), ML-20M shape rank %d' % cfg['rank'],
             'value': engine.nnz * sweeps_per_sec,
             'unit': 'nnz/s',
             'sweeps_per_sec': sweeps_per_sec,
