@@ -102,6 +102,9 @@ def main():
                     help='fraction of rows the CPU baseline is timed on (0 disables it)')
     args = ap.parse_args()
 
+    if os.environ.get('ALSMI_BENCH_WATCHDOG'):  # debugging aid: traceback + exit after N s
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['ALSMI_BENCH_WATCHDOG']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank_id = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -109,13 +112,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
         args.gpus = world
+    # ALSMI_DIST_BACKEND=gloo lets several ranks share one GPU (a rehearsal of the multi-rank
+    # path on a one-GPU box; RCCL wants one device per rank)
+    backend = os.environ.get('ALSMI_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from alsmi import synth

@@ -8,6 +8,8 @@ and each half-sweep ends with an all-gather of the updated factor rows (RCCL ove
 xGMI when the backend is "nccl"), the training error with an all-reduce of the
 squared-error sum.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -91,7 +93,8 @@ class AlsEngine(object):
         # for), so with several ranks the user half runs as a few row slabs, balanced by
         # entries, and the gather of one slab travels while the next is computed.
         if user_slabs is None:
-            user_slabs = 1 if self.world == 1 else 4
+            user_slabs = int(os.environ.get('ALSMI_USER_SLABS', '0')) or \
+                (1 if self.world == 1 else 4)
         self.u_sub = split_by_nnz(self.csr.indptr_host, max(1, int(user_slabs)))
         self.plans_u = [b.make_plan(self.csr, self.rank, chunk, int(lo), int(hi))
                         for lo, hi in zip(self.u_sub[:-1], self.u_sub[1:])]
@@ -196,12 +199,16 @@ class AlsEngine(object):
         send[:int(sizes[self.me])].copy_(table[mlo:mlo + int(sizes[self.me])])
         recv = torch.empty((self.world * width, table.shape[1]), dtype=table.dtype,
                            device=table.device)
-        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
-        return work, recv, send, lo, sizes, width
+        # asynchronous where that is the backend's normal mode (RCCL; gloo on host tensors);
+        # gloo with device tensors does not complete an asynchronous gather
+        overlap = dist.get_backend(self.group) == 'nccl' or not table.is_cuda
+        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=overlap)
+        return (work if overlap else None), recv, send, lo, sizes, width
 
     def _finish_slab_gather(self, table, pending):
         work, recv, _send, lo, sizes, width = pending
-        work.wait()
+        if work is not None:
+            work.wait()
         for r in range(self.world):
             if r != self.me and sizes[r]:
                 table[int(lo[r]):int(lo[r] + sizes[r])].copy_(
