@@ -63,36 +63,58 @@ class ALS(BaseEstimator):
         _, _ = self.fit_transform(X, y, shape=shape)
         return self
 
+    # ``data`` (the ratings as a scipy CSR matrix, src/als.py:142) is built on the device; the
+    # host copy is only materialised when something reads it.
+    @property
+    def data(self):
+        if getattr(self, '_data', None) is None and getattr(self, '_data_dev', None) is not None:
+            (indptr, indices, vals), shape = self._data_dev
+            self._data = sps.csr_matrix((vals.cpu().numpy(), indices.cpu().numpy(),
+                                         indptr.cpu().numpy()), shape=shape)
+            self._data_dev = None
+        return getattr(self, '_data', None)
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+        self._data_dev = None
+
+    def __getstate__(self):
+        _ = self.data  # pickles carry the host matrix, never device tensors
+        state = dict(self.__dict__)
+        state.pop('_data_dev', None)
+        return state
+
     def _build_data(self, X, y, shape):
-        """Ratings as a canonical CSR matrix (src/als.py:132-142)."""
+        """Ratings in canonical CSR form (src/als.py:132-142).  Returns
+        ``(csr, shape, item_avg, dev_pairs)``: csr = (indptr, indices, vals) on the device for
+        triplet input (then dev_pairs holds the uploaded triplets) or on the host for a sparse
+        ``y``; item_avg = mean stored rating per item (0 for an unrated one)."""
         if (y.ndim < 2 or y.shape[0] == 1) and not shape:
             raise ValueError('When y is a scalar or 1-D array shape must be' +
                              'provided.')
         users, items = _check_x(X)
         if not sps.issparse(y):
+            import torch
             # triplets -> CSR on the device (last write wins, zeros dropped, sorted columns)
-            indptr, indices, vals = dev.build_csr(users, items, y, shape, np.float64,
-                                                  dev.require_gpu())
-            data = sps.csr_matrix((vals.cpu().numpy(), indices.cpu().numpy(),
-                                   indptr.cpu().numpy()), shape=tuple(int(v) for v in shape))
-        else:
-            data = y.tocsr().astype(np.float64)
-            if data is y:
-                data = data.copy()
-            data.sum_duplicates()
-            data.eliminate_zeros()
-            data.sort_indices()
-        return data
-
-    def fit_transform(self, X, y, shape=None):
-        """Factorise the ratings; returns ``(user_feats, item_feats)`` of shapes
-        (rank, n_users) and (rank, n_items) (src/als.py:109-171)."""
-        data = self._build_data(X, y, shape)
-        random_state = check_random_state(self.random_state)
-        n, m = data.shape
-
-        # initial factors: uniform random items with row 0 = mean rating of the
-        # item, zero users (src/als.py:143-152); the MT19937 stream stays on the host
+            shape = tuple(int(v) for v in shape)
+            pairs = dev.upload_triplets(users, items, y, shape, dev.require_gpu())
+            csr = dev.build_csr_device(*pairs, shape, np.float64)
+            m = shape[1]
+            cols = csr[1].to(torch.int64)
+            counts = torch.bincount(cols, minlength=m).to(torch.float64)
+            sums = torch.zeros(m, dtype=torch.float64, device=cols.device).index_add_(0, cols, csr[2])
+            item_avg = torch.where(counts > 0, sums / counts.clamp_min(1),
+                                   torch.zeros_like(sums)).cpu().numpy()
+            self._data, self._data_dev = None, (csr, shape)
+            return csr, shape, item_avg, pairs
+        data = y.tocsr().astype(np.float64)
+        if data is y:
+            data = data.copy()
+        data.sum_duplicates()
+        data.eliminate_zeros()
+        data.sort_indices()
+        m = data.shape[1]
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             counts = np.bincount(data.indices, minlength=m)
@@ -100,12 +122,22 @@ class ALS(BaseEstimator):
             with np.errstate(invalid='ignore', divide='ignore'):
                 item_avg = sums / counts
         item_avg[np.isnan(item_avg)] = 0
+        self.data = data
+        return (data.indptr, data.indices, data.data), data.shape, item_avg, None
+
+    def fit_transform(self, X, y, shape=None):
+        """Factorise the ratings; returns ``(user_feats, item_feats)`` of shapes
+        (rank, n_users) and (rank, n_items) (src/als.py:109-171)."""
+        csr, (n, m), item_avg, dev_pairs = self._build_data(X, y, shape)
+        random_state = check_random_state(self.random_state)
+
+        # initial factors: uniform random items with row 0 = mean rating of the
+        # item, zero users (src/als.py:143-152); the MT19937 stream stays on the host
         self.item_feats = random_state.rand(self.rank, m)
         self.item_feats[0] = item_avg
         self.user_feats = np.zeros((self.rank, n))
-        self.data = data
 
-        engine = AlsEngine.from_global(data.indptr, data.indices, data.data, (n, m), self.rank,
+        engine = AlsEngine.from_global(csr[0], csr[1], csr[2], (n, m), self.rank,
                                        self.alpha, dtype=self.dtype, group=_default_group())
         engine.set_factors(self.user_feats, self.item_feats)
         # The error of sweep s is produced by the user half of sweep s+1, which reads the
@@ -152,7 +184,14 @@ class ALS(BaseEstimator):
             record(engine.train_rmse())
         self.n_iter_ = sweeps
         self.user_feats, self.item_feats = engine.get_factors()
-        self.reconstruction_err_ = self.score(X, y)
+        if dev_pairs is not None and dev_pairs[0].numel() > 0:
+            # score(X, y) (src/als.py:169) on the triplets and factor tables still on the device
+            du, di, dy = dev_pairs
+            _, sse = dev.sddmm(self.rank, du, di, engine.U, engine.V, dy.to(engine.U.dtype),
+                               want_pred=False)
+            self.reconstruction_err_ = -float(np.sqrt(float(sse.cpu()[0]) / du.numel()))
+        else:
+            self.reconstruction_err_ = self.score(X, y)
         return self.user_feats, self.item_feats
 
     # -------------------------------------------------------------- predict

@@ -50,7 +50,7 @@ def factors_to_device(feats, dtype, device):
 
 def factors_to_host(table, rank):
     """[n x ld] device table -> (rank, n) float64 C-order host array."""
-    return np.ascontiguousarray(table[:, :rank].to(torch.float64).cpu().numpy().T)
+    return table[:, :rank].t().contiguous().to(torch.float64).cpu().numpy()  # transposed on the device
 
 
 def _as_device(a, tdtype, device):
@@ -239,10 +239,9 @@ def _sparse_workspace(n_entries, device):
     return ws
 
 
-def build_csr(users, items, y, shape, dtype, device):
-    """Ratings triplets -> CSR on the device, with the reference's lil-fill semantics
-    (src/als.py:137-140).  users/items/y are host arrays.  Returns device tensors
-    (indptr int64 [n+1], indices int32 [nnz], vals dtype [nnz])."""
+def upload_triplets(users, items, y, shape, device):
+    """Host (users, items, y) -> device (int32, int32, float64) with the reference's index
+    rules (negative indices wrap, out-of-range raises IndexError)."""
     n, m = int(shape[0]), int(shape[1])
     users = np.asarray(users).ravel()
     items = np.asarray(items).ravel()
@@ -252,13 +251,21 @@ def build_csr(users, items, y, shape, dtype, device):
     if users.size and (users.min() < -n or users.max() >= n or
                        items.min() < -m or items.max() >= m):
         raise IndexError('index out of bounds for shape {}'.format((n, m)))
-    users = np.where(users < 0, users + n, users).astype(np.int32)
-    items = np.where(items < 0, items + m, items).astype(np.int32)
-    n_in = int(users.size)
+    d_users = torch.from_numpy(np.ascontiguousarray(users)).to(device)
+    d_items = torch.from_numpy(np.ascontiguousarray(items)).to(device)
+    d_users = torch.where(d_users < 0, d_users + n, d_users).to(torch.int32)
+    d_items = torch.where(d_items < 0, d_items + m, d_items).to(torch.int32)
+    return d_users, d_items, torch.from_numpy(y).to(device)
+
+
+def build_csr_device(d_users, d_items, d_y, shape, dtype):
+    """Device triplets -> CSR on the device, with the reference's lil-fill semantics
+    (src/als.py:137-140).  Returns device tensors (indptr int64 [n+1], indices int32 [nnz],
+    vals dtype [nnz])."""
+    n, m = int(shape[0]), int(shape[1])
+    device = d_users.device
+    n_in = int(d_users.numel())
     td = torch_dtype(dtype)
-    d_users = torch.from_numpy(users).to(device)
-    d_items = torch.from_numpy(items).to(device)
-    d_y = torch.from_numpy(y).to(device)
     indptr = torch.empty(n + 1, dtype=torch.int64, device=device)
     indices = torch.empty(max(n_in, 1), dtype=torch.int32, device=device)
     vals = torch.empty(max(n_in, 1), dtype=td, device=device)
@@ -269,6 +276,11 @@ def build_csr(users, items, y, shape, dtype, device):
         _ptr(indices), _ptr(vals), _ptr(nnz), _ptr(ws), _stream()), 'alsmi_build_csr')
     count = int(nnz.cpu()[0])
     return indptr, indices[:count].contiguous(), vals[:count].contiguous()
+
+
+def build_csr(users, items, y, shape, dtype, device):
+    """Ratings triplets (host arrays) -> CSR on the device; see build_csr_device."""
+    return build_csr_device(*upload_triplets(users, items, y, shape, device), shape, dtype)
 
 
 def csr_to_csc(indptr, indices, vals, shape):
