@@ -15,15 +15,8 @@ from sklearn.base import BaseEstimator
 from sklearn.utils.validation import check_is_fitted, check_random_state
 
 from . import device as dev
-from .engine import AlsEngine
+from .engine import AlsEngine, default_group as _default_group
 from .utils import _check_x, _check_y, root_mean_squared_error
-
-
-def _default_group():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.group.WORLD
-    return None
 
 
 class ALS(BaseEstimator):

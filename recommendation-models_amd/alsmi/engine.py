@@ -16,6 +16,14 @@ import torch
 from . import device as dev
 
 
+def default_group():
+    """The world group when torch.distributed runs with more than one rank, else None."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.group.WORLD
+    return None
+
+
 def split_by_nnz(indptr, parts):
     """Boundaries of ``parts`` contiguous row ranges with (almost) equal numbers of
     stored entries: int64 array of parts+1 row ids."""

@@ -27,6 +27,7 @@ from sklearn.utils.validation import check_is_fitted
 
 from . import _lib
 from . import device as dev
+from .engine import default_group
 from .utils import _check_x, root_mean_squared_error
 
 INTEGER_TYPES = (numbers.Integral, np.integer)
@@ -35,9 +36,21 @@ INTEGER_TYPES = (numbers.Integral, np.integer)
 class ImcProblem(object):
     """Device-resident IMC data in index form and the three evaluations on it."""
 
-    def __init__(self, X_attrs, Y_attrs, users, items, ratings, dtype=np.float64):
+    def __init__(self, X_attrs, Y_attrs, users, items, ratings, dtype=np.float64, group=None,
+                 shard=None):
+        """group: a torch.distributed process group; each rank then keeps the samples of one
+        contiguous user range (balanced by samples) and every evaluation ends with an
+        all-reduce of the p x q result and of the scalar, so all ranks see identical values
+        and drive identical optimiser trajectories.  shard = (index, count) selects such a
+        range without a group (the caller combines the partial results itself)."""
         import torch
         self.device = dev.require_gpu()
+        self.group = group
+        if group is not None:
+            import torch.distributed as dist
+            shard = (dist.get_rank(group), dist.get_world_size(group))
+            if shard[1] == 1:
+                self.group, shard = None, None
         self.dtype = np.dtype(dtype)
         lib = _lib.load()
         X_attrs = np.atleast_2d(np.asarray(X_attrs, dtype=np.float64))
@@ -62,15 +75,31 @@ class ImcProblem(object):
         np.cumsum(np.bincount(users, minlength=self.n_users), out=indptr[1:])
         td = dev.torch_dtype(self.dtype)
         to = lambda a, t: torch.from_numpy(np.ascontiguousarray(a)).to(self.device, t)
+        items_g, ratings_g = items[self.order].astype(np.int32), ratings[self.order]
+        # this rank's users [ulo, uhi) and their samples [slo, shi) of the grouped order
+        self.ulo, self.uhi, self.slo, self.shi = 0, self.n_users, 0, self.n_samples
+        if shard is not None:
+            from .engine import split_by_nnz
+            bounds = split_by_nnz(indptr, int(shard[1]))
+            self.ulo, self.uhi = int(bounds[shard[0]]), int(bounds[shard[0] + 1])
+            self.slo, self.shi = int(indptr[self.ulo]), int(indptr[self.uhi])
+            indptr = indptr[self.ulo:self.uhi + 1] - self.slo
+            items_g, ratings_g = items_g[self.slo:self.shi], ratings_g[self.slo:self.shi]
+            X_attrs = X_attrs[self.ulo:self.uhi]
+            # keep only the item rows this rank's samples refer to
+            uniq, inv = np.unique(items_g, return_inverse=True)
+            Y_attrs, items_g = Y_attrs[uniq], inv.astype(np.int32)
+        self.n_local_users = self.uhi - self.ulo
+        self.n_local_samples = self.shi - self.slo
         self.indptr = to(indptr, torch.int64)
-        self.items = to(items[self.order].astype(np.int32), torch.int32)
-        self.ratings = to(ratings[self.order], td)
+        self.items = to(items_g, torch.int32)
+        self.ratings = to(ratings_g, td)
         self.X = to(X_attrs, td)
-        ypad = np.zeros((self.n_items, self.ld))
+        ypad = np.zeros((Y_attrs.shape[0], self.ld))
         ypad[:, :self.q] = Y_attrs
         self.Y = to(ypad, td)
-        nbytes = int(lib.alsmi_imc_workspace_bytes(_lib.dtype_code(self.dtype), self.n_users,
-                                                   self.p, self.q))
+        nbytes = int(lib.alsmi_imc_workspace_bytes(_lib.dtype_code(self.dtype),
+                                                   max(self.n_local_users, 1), self.p, self.q))
         self.workspace = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self.device)
         self._torch = torch
         self._td = td
@@ -79,21 +108,29 @@ class ImcProblem(object):
         torch = self._torch
         M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(self.p, self.q))
         Md = torch.from_numpy(M).to(self.device, self._td)
-        out = torch.empty((self.p, self.q), dtype=self._td, device=self.device) \
+        out = torch.zeros((self.p, self.q), dtype=self._td, device=self.device) \
             if want_out else None
         sse = torch.zeros(1, dtype=torch.float64, device=self.device) if want_sse else None
-        pred = torch.empty(self.n_samples, dtype=self._td, device=self.device) \
+        # predictions: this rank fills its samples' slots of the full (grouped) vector
+        pred = torch.zeros(self.n_samples, dtype=self._td, device=self.device) \
             if want_pred else None
         r = self.ratings if ratings is None else ratings
         if self.n_users == 0 or self.n_samples == 0:
             zero = np.zeros((self.p, self.q))
             return (zero if want_out else None, 0.0 if want_sse else None,
                     np.zeros(0) if want_pred else None)
-        _lib.check(_lib.load().alsmi_imc_eval(
-            _lib.dtype_code(self.dtype), int(mode), self.n_users, self.p, self.q,
-            dev._ptr(self.indptr), dev._ptr(self.items), dev._ptr(r), dev._ptr(self.X),
-            dev._ptr(self.Y), dev._ptr(Md), dev._ptr(out), dev._ptr(pred), dev._ptr(sse),
-            dev._ptr(self.workspace), dev._stream()), 'alsmi_imc_eval')
+        if self.n_local_users > 0 and self.n_local_samples > 0:
+            local_pred = pred[self.slo:self.shi] if want_pred else None
+            _lib.check(_lib.load().alsmi_imc_eval(
+                _lib.dtype_code(self.dtype), int(mode), self.n_local_users, self.p, self.q,
+                dev._ptr(self.indptr), dev._ptr(self.items), dev._ptr(r), dev._ptr(self.X),
+                dev._ptr(self.Y), dev._ptr(Md), dev._ptr(out), dev._ptr(local_pred),
+                dev._ptr(sse), dev._ptr(self.workspace), dev._stream()), 'alsmi_imc_eval')
+        if self.group is not None:
+            import torch.distributed as dist
+            for t in (out, sse, pred):
+                if t is not None:
+                    dist.all_reduce(t, group=self.group)
         out_h = out.to(torch.float64).cpu().numpy() if want_out else None
         sse_h = float(sse.cpu()[0]) if want_sse else None
         pred_h = None
@@ -125,7 +162,7 @@ class ImcProblem(object):
 
     def init_z(self):
         """src/imc.py:157-159: X^T diag(R) Y / R.size pushed through an SVD."""
-        neg = -self.ratings
+        neg = -self.ratings  # (the local samples; the evaluation sums over the ranks)
         out, _, _ = self._eval(0, np.zeros((self.p, self.q)), ratings=neg)
         z0 = out / self.n_samples
         u, s, v = np.linalg.svd(z0, False)
@@ -143,12 +180,13 @@ class ImcProblem(object):
 
 def problem_from_samples(users, items, ratings, dtype=np.float64):
     """Per-sample feature matrices (the reference's form) as an index-form problem
-    in which every sample is its own 'user' and its own 'item'."""
+    in which every sample is its own 'user' and its own 'item'.  With an initialised
+    torch.distributed group of several ranks the samples are sharded over the ranks."""
     users = np.atleast_2d(np.asarray(users))
     items = np.atleast_2d(np.asarray(items))
     n_s = users.shape[0]
     idx = np.arange(n_s)
-    return ImcProblem(users, items, idx, idx, ratings, dtype=dtype)
+    return ImcProblem(users, items, idx, idx, ratings, dtype=dtype, group=default_group())
 
 
 _problem_cache = {}
@@ -235,7 +273,8 @@ class IMC(BaseEstimator):
         if issparse(y):
             y = y.tocsr()
             rows, cols = y.nonzero()
-            return ImcProblem(x, y_, rows, cols, np.asarray(y[rows, cols]).ravel())
+            return ImcProblem(x, y_, rows, cols, np.asarray(y[rows, cols]).ravel(),
+                              group=default_group())
         return problem_from_samples(x, y_, y)
 
     def fit_transform(self, X, y, Z=None):

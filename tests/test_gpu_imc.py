@@ -183,3 +183,40 @@ def test_dimc_matches_reference(gpu, golden):
     np.testing.assert_allclose(d.reconstruction_err_, g['rnd_err'], rtol=1e-6)
     np.testing.assert_allclose(d.predict((g['rnd_X'][users], g['rnd_Y'][items], users, items)),
                                g['rnd_predict'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('parts', [2, 3, 5])
+def test_sharded_evaluations_add_up(gpu, parts):
+    """The multi-rank form of the IMC evaluations: each rank keeps one contiguous user range
+    (and only the item rows its samples touch); the partial gradients, Hessian-vector
+    products, squared errors and predictions of the shards add up to the unsharded result
+    (on several ranks that sum is an all-reduce)."""
+    from alsmi.imc import ImcProblem
+    rng = np.random.default_rng(7)
+    n, m, p, q, ns = 90, 70, 9, 21, 900
+    X, Y = rng.standard_normal((n, p)), rng.standard_normal((m, q))
+    users, items = rng.integers(0, n, ns), rng.integers(0, m, ns)
+    users[users == 5] = 6            # a user without samples
+    r = rng.standard_normal(ns)
+    Z, S = rng.standard_normal((p, q)), rng.standard_normal((p, q))
+    whole = ImcProblem(X, Y, users, items, r)
+    g0, sse0, pred0 = whole._eval(0, Z, want_sse=True, want_pred=True)
+    h0, _, _ = whole._eval(1, S)
+    z0 = whole.init_z()
+    g, h, sse, pred, zinit = 0.0, 0.0, 0.0, 0.0, 0.0
+    seen = 0
+    for i in range(parts):
+        part = ImcProblem(X, Y, users, items, r, shard=(i, parts))
+        gi, si, pi = part._eval(0, Z, want_sse=True, want_pred=True)
+        hi, _, _ = part._eval(1, S)
+        zi, _, _ = part._eval(0, np.zeros((p, q)), ratings=-part.ratings)
+        g, h, sse, pred, zinit = g + gi, h + hi, sse + si, pred + pi, zinit + zi
+        seen += part.n_local_samples
+        assert part.Y.shape[0] <= m
+    assert seen == ns
+    np.testing.assert_allclose(g, g0, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(h, h0, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(sse, sse0, rtol=1e-12)
+    np.testing.assert_allclose(pred, pred0, rtol=1e-12, atol=1e-13)
+    u, sv, v = np.linalg.svd(zinit / ns, False)
+    np.testing.assert_allclose(u.dot(np.diag(sv)).dot(v), z0, rtol=1e-10, atol=1e-12)
