@@ -738,79 +738,9 @@ struct GjStep<T, KP, KP> {
     static __device__ __forceinline__ void run(T (&)[KP], T &, T &, int &, int) {}
 };
 
-// Gauss-Jordan step with the pivot row fetched through LDS instead of v_readlane: column P is
-// written once (one element per lane), then every lane reads the entries it needs back with
-// broadcast 16-byte reads — all of a step's reads are issued together, ahead of the arithmetic
-// — and updates two columns per v_pk_fma_f32.  A vector-ALU instruction costs about four
-// cycles of issue here whatever it does, so halving their number is what pays.  Columns <= P
-// are dead after step P (nothing reads them again), so whole aligned groups of four are
-// updated without masking.  `col` is a wave-private LDS vector of KP elements.
-template <int KP, int P, int CH, int SPCT>
-struct GjStepPk {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ void run(f2 (&a)[KP / 2], float &bb, float &dinv, int &bad,
-                                               int lane, float *col) {
-        constexpr int G0 = (P + 1) / 4;      // first group of four holding a column > P
-        constexpr int NG = KP / 4 - G0;      // groups to update
-        // The broadcast reads return 16 bytes to each of 64 lanes and the LDS of a CU delivers
-        // 128 bytes per cycle to its four SIMDs together, which bounds a solve that fetches
-        // every pivot entry that way.  SPCT percent of the groups therefore take their four
-        // entries through v_readlane into scalar registers instead (vector-ALU issue, no LDS).
-        constexpr int NS = (NG * SPCT + 50) / 100;
-        const float u = a[P / 2][P & 1];
-        if (lane < KP) col[lane] = u;
-        const float d = read_lane(u, P);
-        bad |= (d > 0.0f) ? 0 : 1;
-        const float inv = pivot_rcp(d);
-        const float zp = read_lane(bb, P);
-        const bool me = lane == P;
-        const float m = me ? 0.0f : u * inv;
-        dinv = me ? inv : dinv;
-        bb -= m * zp;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const f2 mm = {-m, -m};
-#pragma unroll
-        for (int h = 0; h < NS; ++h) {
-            const int c = 4 * (G0 + h);
-            const f2 lo = {read_lane(u, c), read_lane(u, c + 1)};
-            const f2 hi = {read_lane(u, c + 2), read_lane(u, c + 3)};
-            a[c / 2] = __builtin_elementwise_fma(mm, lo, a[c / 2]);
-            a[c / 2 + 1] = __builtin_elementwise_fma(mm, hi, a[c / 2 + 1]);
-        }
-        // at most CH groups (4*CH values) of reads in flight, to bound the registers they hold
-#pragma unroll
-        for (int h0 = NS; h0 < NG; h0 += CH) {
-            f4 sc[CH];
-#pragma unroll
-            for (int g4 = 0; g4 < CH; ++g4)
-                if (h0 + g4 < NG)
-                    sc[g4] = *reinterpret_cast<const f4 *>(col + 4 * (G0 + h0 + g4));
-#pragma unroll
-            for (int g4 = 0; g4 < CH; ++g4)
-                if (h0 + g4 < NG) {
-                    const int c2 = 2 * (G0 + h0 + g4);
-                    const f2 lo = {sc[g4][0], sc[g4][1]}, hi = {sc[g4][2], sc[g4][3]};
-                    a[c2] = __builtin_elementwise_fma(mm, lo, a[c2]);  // A[P][c] = A[c][P]
-                    a[c2 + 1] = __builtin_elementwise_fma(mm, hi, a[c2 + 1]);
-                }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        GjStepPk<KP, P + 1, CH, SPCT>::run(a, bb, dinv, bad, lane, col);
-    }
-};
-template <int KP, int CH, int SPCT>
-struct GjStepPk<KP, KP, CH, SPCT> {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ void run(f2 (&)[KP / 2], float &, float &, int &, int,
-                                               float *) {}
-};
-
 // Solve from the accumulators; x_out is the solution component of row `lane`.
 // Returns false when a pivot is not positive.
-template <typename T, int NV, int READS_IN_FLIGHT, int SPCT>
+template <typename T, int NV>
 __device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int lane, int rank,
                                          T ridge, T &x_out) {
     constexpr int KP = NV * 16;
@@ -820,15 +750,7 @@ __device__ __forceinline__ bool gj_solve(Gram<T, NV> &G, T *stage, T *bsm, int l
     rows_to_regs<T, NV>(G, stage, bsm, lane, a, bb);
     T dinv = T(1);
     int bad = 0;  // bitwise, so that no step is skipped through an early-out branch
-    if constexpr (sizeof(T) == 4) {
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        f2 a2[KP / 2];
-#pragma unroll
-        for (int c = 0; c < KP / 2; ++c) a2[c] = f2{a[2 * c], a[2 * c + 1]};
-        GjStepPk<KP, 0, READS_IN_FLIGHT, SPCT>::run(a2, bb, dinv, bad, lane, stage);  // stage is free
-    } else {
-        GjStep<T, KP, 0>::run(a, bb, dinv, bad, lane);
-    }
+    GjStep<T, KP, 0>::run(a, bb, dinv, bad, lane);
     x_out = bb * dinv;
     return bad == 0;
 }
@@ -1125,7 +1047,10 @@ struct SolveArgs {
 template <typename T, int KP, bool DUMP>
 struct WaveLds {
     static constexpr bool FAST = !DUMP && (KP <= 64 || (sizeof(T) == 4 && KP <= 128));
-    static constexpr int WORK = FAST ? Stage<T, KP < 64 ? KP : 64>::ELEMS : Slab<T, KP>::ELEMS;
+    // work area: fp32 fast path = the row's current vector (error variant) only; fp64 fast
+    // path = the transposition stage; otherwise the whole matrix
+    static constexpr int WORK = FAST ? (sizeof(T) == 4 ? KP : Stage<T, KP < 64 ? KP : 64>::ELEMS)
+                                     : Slab<T, KP>::ELEMS;
     // + 64 doubles behind the work area: the lanes' squared-error partial sums
     static constexpr int ELEMS = (WORK + 1) / 2 * 2 + 512 / (int)sizeof(T);
     static constexpr size_t BYTES = (size_t)ELEMS * sizeof(T);
@@ -1135,8 +1060,7 @@ struct WaveLds {
 // ABLATE selects a diagnostic build used only for timing experiments (env ALSMI_ABLATE, f32
 // rank 64): 1 = accumulate but skip the solve, 2 = solve but skip the accumulation, 4 = Gram
 // build on the fp32 MFMA, 10 = on the bf16 matrix cores with the exact three-way split (both
-// kernels), 8 = the Gauss-Jordan solve of the fp64 path instead of the matrix-core block
-// solve.  The production kernel is the ABLATE = 0 instantiation and contains none of that code.
+// kernels).  The production kernel is the ABLATE = 0 instantiation and contains none of that code.
 // ERR builds also sum (rating - <current vector, neighbour>)^2 over every entry they read: the
 // training error of the factors BEFORE this half-sweep, at no extra memory traffic.
 template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0, bool ERR = false>
@@ -1216,7 +1140,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             continue;
         }
         const T ridge = p.alpha * (T)(end - beg) * s2;
-        if constexpr (FAST && sizeof(T) == 4 && ABLATE != 8) {
+        if constexpr (FAST && sizeof(T) == 4) {
             float xs[NV];
             const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs);
             if (lane < 16) {
@@ -1232,7 +1156,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             continue;
         } else if constexpr (FAST) {
             T x;
-            const bool ok = gj_solve<T, NV, 4, 0>(G, Asm, bsm, lane, p.rank, ridge, x);
+            const bool ok = gj_solve<T, NV>(G, Asm, bsm, lane, p.rank, ridge, x);
             if (lane < KP) out[lane] = ok ? x : T(0);
             continue;
         }
@@ -1301,7 +1225,6 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, double 
             if (ablate == 1) kern = solve_rows_kernel<T, NV, WPB, false, 1>;
             if (ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
             if (ablate == 4) kern = solve_rows_kernel<T, NV, WPB, false, 4>;
-            if (ablate == 8) kern = solve_rows_kernel<T, NV, WPB, false, 8>;
             if (ablate == 10) kern = solve_rows_kernel<T, NV, WPB, false, 10>;
         }
     }
