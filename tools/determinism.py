@@ -12,7 +12,8 @@ for p in (ROOT, os.path.join(ROOT, 'recommendation-models_amd'), os.path.join(RO
 from alsmi import device as dev, synth  # noqa: E402
 
 device = dev.require_gpu()
-for (n, m, nnz, rank) in ((138493, 26744, 20000000, 64), (138493, 26744, 20000000, 64)):
+for (n, m, nnz, rank) in ((138493, 26744, 20000000, 64), (138493, 26744, 20000000, 10),
+                          (138493, 26744, 20000000, 32), (138493, 26744, 20000000, 128)):
     prob = synth.sharded_problem(20242, n, m, nnz, 1, 0, device)
     for name, tri, ncols in (('user', prob['csr'], m), ('item', prob['csc'], n)):
         side = dev.SparseSide(tri[0], tri[1], tri[2], len(tri[0]) - 1, ncols, 'float32', device)
