@@ -36,6 +36,9 @@ CONFIGS = {
     'r128': dict(n=138493, m=26744, nnz=20000000, rank=128,
                  workload='ALS rank 128, synthetic ML-20M shape 138493x26744, 20M nnz per GPU '
                           '(single-GPU slice of the rank-128 configuration)'),
+    'c4slice': dict(n=1250000, m=1000000, nnz=125000000, rank=128,
+                    workload='ALS rank 128, one GPU\'s share of the 10M x 1M, 1B-entry configuration '
+                             'at 8 GPUs: 1.25M users x 1M items, 125M nnz'),
     'small': dict(n=20000, m=5000, nnz=1000000, rank=64,
                   workload='ALS rank 64, synthetic 20000x5000, 1M nnz per GPU (smoke size)'),
 }
