@@ -78,7 +78,7 @@ int alsmi_plan_info(const alsmi_plan *plan, int64_t *n_rows, int64_t *n_heavy_ro
  * (src/als.py:243-247); an empty row or a matrix that is not positive definite
  * gives a zero vector (the reference's LinAlgError branch, src/als.py:248-249).
  * Rows outside the plan's range are not touched.
- * ALSMI_F32 with rank <= 64: the products f f^T are formed on the fp16 matrix cores
+ * ALSMI_F32: the products f f^T are formed on the fp16 matrix cores
  * from values scaled by a power of two taken from the largest |element| of the
  * source table (read once per call); the result has fp32 accuracy for
  * 2^-40 <= max|src| <= 2^40 and a source table of at most 4 GiB, elements below
