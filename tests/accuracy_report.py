@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Measured accuracy of the fp32 half-sweep against the fp64 oracle (run on the GPU box):
+"""Test aid (not collected by pytest): measured accuracy of the fp32 half-sweep against the fp64
+oracle, run by hand on the GPU box:
 worst and median relative error per factor vector for a few seeded problems."""
 import os
 import sys
@@ -7,7 +8,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, 'recommendation-models_amd'), os.path.join(ROOT, 'tests')):
+for p in (ROOT, os.path.join(ROOT, 'recommendation-models_amd'), os.path.join(ROOT, 'tests')):  # noqa
     sys.path.insert(0, p)
 
 from problems import random_problem  # noqa: E402
