@@ -516,11 +516,14 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const float *__restrict__ 
 #ifndef SOLVE_MIN_WAVES
 #define SOLVE_MIN_WAVES 3
 #endif
+#ifndef R128_MIN_WAVES
+#define R128_MIN_WAVES 1
+#endif
 
 // ---- kernel 1: partial normal equations of the chunks of long rows ---------------------
 // ERR: also the chunk's sum of squared ratings (last slab slot).
 template <typename T, int NV, int MODE, bool ERR = false>
-__global__ __launch_bounds__(256, (NV == 4 ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES : 2) : 1)) void gram_chunks_kernel(
+__global__ __launch_bounds__(256, (NV == 4 ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES : 2) : (NV == 8 && sizeof(T) == 4 && MODE == GRAM_F16X2 ? R128_MIN_WAVES : 1))) void gram_chunks_kernel(
     const int64_t *__restrict__ ch_beg, const int64_t *__restrict__ ch_end, int n_chunks,
     const int32_t *__restrict__ indices, const T *__restrict__ vals, const T *__restrict__ src,
     const unsigned *__restrict__ max_bits, T *__restrict__ slabs) {
@@ -1064,7 +1067,7 @@ struct WaveLds {
 // ERR builds also sum (rating - <current vector, neighbour>)^2 over every entry they read: the
 // training error of the factors BEFORE this half-sweep, at no extra memory traffic.
 template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0, bool ERR = false>
-__global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES : 2) : 1)) void solve_rows_kernel(
+__global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES : 2) : (NV == 8 && !DUMP && sizeof(T) == 4 ? R128_MIN_WAVES : 1))) void solve_rows_kernel(
     SolveArgs<T> p) {
     constexpr int KP = NV * 16;
     constexpr int LD = Slab<T, KP>::LD;
