@@ -828,7 +828,7 @@ __device__ __forceinline__ f4 mfma_xty(f4 x, f4 y, f4 c) {
 
 // Lane constants of the block solver.
 struct SolveLane {
-    int g, q, irow, addr_row, addr_col;
+    int lane, g, q, irow, addr_row, addr_col;
     bool last_col;
 };
 
@@ -839,7 +839,7 @@ template <int NV, int K>
 struct PivotBlock {
     static __device__ __forceinline__ void run(Gram<float, NV> &G, const SolveLane &L,
                                                float (&y)[NV], f4 (&rs)[NV], f4 (&zr)[NV],
-                                               int &bad) {
+                                               int &bad, float *stash) {
         const int g = L.g, q = L.q;
         // R starts as the identity.  Its last column stays e_15 whatever the row operations, so
         // it carries the right-hand side instead: the same operations turn y into inv(L) y.
@@ -897,21 +897,36 @@ struct PivotBlock {
             for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
             y[i] -= col_allreduce(part);
         }
-        PivotBlock<NV, K + 1>::run(G, L, y, rs, zr, bad);
+        if (stash) {  // keep the block's back-substitution data in LDS instead of registers
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                stash[((K * 8) + r) * WAVE + L.lane] = rs[K][r];
+                stash[((K * 8) + 4 + r) * WAVE + L.lane] = zr[K][r];
+            }
+        }
+        PivotBlock<NV, K + 1>::run(G, L, y, rs, zr, bad, stash);
     }
 };
 template <int NV>
 struct PivotBlock<NV, NV> {
     static __device__ __forceinline__ void run(Gram<float, NV> &, const SolveLane &, float (&)[NV],
-                                               f4 (&)[NV], f4 (&)[NV], int &) {}
+                                               f4 (&)[NV], f4 (&)[NV], int &, float *) {}
 };
 
 // Back substitution of block K: x_K = inv(L_KK)^T D^-1 (z_K - sum_J Z_KJ x_J), last block first.
 template <int NV, int K>
 struct BackBlock {
     static __device__ __forceinline__ void run(const Gram<float, NV> &G, const f4 (&rs)[NV],
-                                               const f4 (&zr)[NV], float (&xc)[NV], float &chk) {
-        f4 rhs = zr[K];
+                                               const f4 (&zr)[NV], float (&xc)[NV], float &chk,
+                                               const float *stash, int lane) {
+        f4 rhs = zr[K], rsk = rs[K];
+        if (stash) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rsk[r] = stash[((K * 8) + r) * WAVE + lane];
+                rhs[r] = stash[((K * 8) + 4 + r) * WAVE + lane];
+            }
+        }
         if constexpr (K < NV - 1) {
             f4 w = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -921,10 +936,10 @@ struct BackBlock {
         }
         float part = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part += rs[K][r] * rhs[r];
+        for (int r = 0; r < 4; ++r) part += rsk[r] * rhs[r];
         xc[K] = col_allreduce(part);
         chk += fabsf(xc[K]);
-        if constexpr (K > 0) BackBlock<NV, K - 1>::run(G, rs, zr, xc, chk);
+        if constexpr (K > 0) BackBlock<NV, K - 1>::run(G, rs, zr, xc, chk, stash, lane);
     }
 };
 
@@ -933,12 +948,13 @@ struct BackBlock {
 // not finite.
 template <int NV>
 __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int rank, float ridge,
-                                            float (&xc)[NV]) {
+                                            float (&xc)[NV], float *stash = nullptr) {
     // The lane-dependent constants below are cheap to derive; hiding the lane id from the
     // optimiser keeps them from being hoisted out of the row loop, where they would occupy
     // registers (or spill slots) throughout the accumulation.
     asm volatile("" : "+v"(lane));
     SolveLane L;
+    L.lane = lane;
     L.g = lane >> 4;
     L.q = lane & 15;
     L.irow = 4 * L.g + (L.q & 3);  // the tile row this lane feeds to the 4x4x1 instruction
@@ -953,9 +969,9 @@ __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int ra
     // z_k = inv(L_kk) y_k in the row layout.
     f4 rs[NV], zr[NV];
     int bad = 0;
-    PivotBlock<NV, 0>::run(G, L, y, rs, zr, bad);
+    PivotBlock<NV, 0>::run(G, L, y, rs, zr, bad, stash);
     float chk = 0.0f;
-    BackBlock<NV, NV - 1>::run(G, rs, zr, xc, chk);
+    BackBlock<NV, NV - 1>::run(G, rs, zr, xc, chk, stash, lane);
     return !__any(bad != 0 || !(chk < INFINITY));
 }
 
@@ -1055,7 +1071,11 @@ struct WaveLds {
     static constexpr int WORK = FAST ? (sizeof(T) == 4 ? KP : Stage<T, KP < 64 ? KP : 64>::ELEMS)
                                      : Slab<T, KP>::ELEMS;
     // + 64 doubles behind the work area: the lanes' squared-error partial sums
-    static constexpr int ELEMS = (WORK + 1) / 2 * 2 + 512 / (int)sizeof(T);
+    static constexpr int ERR_AT = (WORK + 1) / 2 * 2;
+    // + (fp32, padded rank 128) the back-substitution data of the eight pivot blocks
+    static constexpr int STASH_AT = ERR_AT + 512 / (int)sizeof(T);
+    static constexpr int ELEMS =
+        STASH_AT + ((sizeof(T) == 4 && KP == 128 && !DUMP) ? 8 * 8 * WAVE : 0);
     static constexpr size_t BYTES = (size_t)ELEMS * sizeof(T);
 };
 
@@ -1087,7 +1107,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
     // This lane's share of the squared error of the wave's rows lives in the wave's LDS area
     // (64 doubles behind the work area), not in two registers across the gather.
     double *lane_err_slot =
-        reinterpret_cast<double *>(Asm + (WaveLds<T, KP, DUMP>::WORK + 1) / 2 * 2) + lane;
+        reinterpret_cast<double *>(Asm + WaveLds<T, KP, DUMP>::ERR_AT) + lane;
     if constexpr (ERR) *lane_err_slot = 0.0;
     for (int t = blockIdx.x * WPB + wl; t < p.n_tasks; t += W) {
         const int row = p.order[t];
@@ -1145,7 +1165,9 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
         const T ridge = p.alpha * (T)(end - beg) * s2;
         if constexpr (FAST && sizeof(T) == 4) {
             float xs[NV];
-            const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs);
+            float *stash = nullptr;
+            if constexpr (KP == 128) stash = reinterpret_cast<float *>(Asm) + WaveLds<T, KP, DUMP>::STASH_AT;
+            const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs, stash);
             if (lane < 16) {
                 typedef float vec_t __attribute__((ext_vector_type(NV)));
                 vec_t v;
