@@ -120,6 +120,19 @@ int alsmi_sddmm(int dtype, int rank, int64_t n_pairs, const int32_t *users,
                 const void *vals, void *pred_out, double *sse_out, void *workspace,
                 void *stream);
 
+/* alsmi_sddmm for callers that cannot allocate or hand over a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  Same arguments and results as alsmi_sddmm without the
+ * workspace: the per-block partial sums live in a 16 KiB device array that is part of the
+ * library image (one copy per GPU, held until the process ends), and the call performs no
+ * hipMalloc / hipFree.  At most ALSMI_SDDMM_NOALLOC_MAX_PAIRS pairs per call (more is
+ * ALSMI_EINVAL).  All calls on one GPU share that array: calls that overlap in time on one
+ * GPU (different streams or threads) race on sse_out; pred_out is unaffected. */
+#define ALSMI_SDDMM_NOALLOC_MAX_PAIRS ((int64_t)1 << 28)
+int alsmi_sddmm_noalloc(int dtype, int rank, int64_t n_pairs, const int32_t *users,
+                        const int32_t *items, const void *row_factors, const void *col_factors,
+                        const void *vals, void *pred_out, double *sse_out, void *stream);
+
 /* Row index of every stored entry of rows [row_begin,row_end) (the `users`
  * array of data.nonzero(), src/als.py:161), written to rows_out[0 .. nnz_local). */
 int alsmi_expand_rows(const int64_t *indptr, int64_t row_begin, int64_t row_end,

@@ -7,11 +7,21 @@
 // step, 64 pairs per index load.  The squared error is accumulated in fp64 and reduced in a
 // fixed order (per-block partial sums, then one block adds the partials), so the result is
 // reproducible for a given n_pairs.
+#include <mutex>
+
 #include "alsmi_common.h"
 
 namespace alsmi {
 
 constexpr int SDDMM_MAX_BLOCKS = 2048;
+
+// Per-block partial sums of alsmi_sddmm_noalloc: device memory that belongs to the library
+// image instead of a caller's workspace (16 KiB on every GPU the library runs on, held until
+// the process ends).  Host code never uses this name as an address; it asks the runtime for
+// the array's address on the current device once (noalloc_scratch) and passes that pointer on.
+static __device__ __align__(256) double scratch[SDDMM_MAX_BLOCKS];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
 
 template <typename T, int NV>
 __device__ __forceinline__ T pair_dot(const T *__restrict__ U, const T *__restrict__ V, int uu,
@@ -147,6 +157,28 @@ static int launch_sddmm(int64_t n_pairs, const int32_t *users, const int32_t *it
     return ALSMI_OK;
 }
 
+// Address of `scratch` on the current device, looked up once per device (each GPU holds its own
+// copy of the array at its own address).
+static int noalloc_scratch(double **out) {
+    static std::mutex lock;
+    static double *per_device[NOALLOC_MAX_DEVICES] = {};
+    int dev = -1;
+    ALSMI_HIP_CHECK(hipGetDevice(&dev));
+    ALSMI_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES,
+                  "alsmi_sddmm_noalloc: device ordinal %d outside 0..%d", dev,
+                  NOALLOC_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> hold(lock);
+    if (!per_device[dev]) {
+        void *ptr = nullptr;
+        ALSMI_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        ALSMI_REQUIRE(ptr, "alsmi_sddmm_noalloc: the scratch array has no address on device %d",
+                      dev);
+        per_device[dev] = static_cast<double *>(ptr);
+    }
+    *out = per_device[dev];
+    return ALSMI_OK;
+}
+
 }  // namespace alsmi
 
 extern "C" {
@@ -187,6 +219,23 @@ int alsmi_sddmm(int dtype, int rank, int64_t n_pairs, const int32_t *users, cons
 #undef ALSMI_CASE
     set_error("alsmi_sddmm: unsupported rank");
     return ALSMI_EINVAL;
+}
+
+int alsmi_sddmm_noalloc(int dtype, int rank, int64_t n_pairs, const int32_t *users,
+                        const int32_t *items, const void *row_factors, const void *col_factors,
+                        const void *vals, void *pred_out, double *sse_out, void *stream) {
+    using namespace alsmi;
+    ALSMI_REQUIRE(n_pairs <= ALSMI_SDDMM_NOALLOC_MAX_PAIRS,
+                  "alsmi_sddmm_noalloc: %lld pairs exceed the limit of %lld of the entry point "
+                  "that allocates nothing; use alsmi_sddmm with a workspace",
+                  (long long)n_pairs, (long long)ALSMI_SDDMM_NOALLOC_MAX_PAIRS);
+    double *ws = nullptr;
+    const int rc = noalloc_scratch(&ws);
+    if (rc != ALSMI_OK) return rc;
+    // Every partial the final sum reads is written by this call's own blocks first (both run
+    // in stream order), so nothing of the previous call's contents has to be cleared.
+    return alsmi_sddmm(dtype, rank, n_pairs, users, items, row_factors, col_factors, vals,
+                       pred_out, sse_out, ws, stream);
 }
 
 int alsmi_expand_rows(const int64_t *indptr, int64_t row_begin, int64_t row_end,
