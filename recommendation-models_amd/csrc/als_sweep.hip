@@ -658,6 +658,22 @@ __device__ __forceinline__ void add_ridge(Gram<T, NV> &G, int lane, int rank, T 
         }
 }
 
+// The same for the neighbour-by-neighbour system of a short row (see solve_rows_dual_kernel):
+// tile (a,a) holds neighbours 16a .. 16a+15, of which the first n_real of the row exist.
+template <int ND>
+__device__ __forceinline__ void add_ridge_dual(Gram<float, ND> &G, int lane, int n_real,
+                                               float ridge) {
+    const int g = lane >> 4, q = lane & 15;
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool diag = 4 * g + r == q;
+            const float add = (16 * a + q < n_real) ? ridge : 1.0f;
+            G.acc[tri_index(a, a, ND)][r] += diag ? add : 0.0f;
+        }
+}
+
 // Accumulator tiles -> one matrix row per lane, NV passes of 16 columns each through the
 // stage.  Pass f moves the columns {c*NV + f}: tiles (e,f) with e <= f are stored as they are,
 // tiles with e > f come from tile (f,e) by symmetry.  a[] ends up in natural column order.
@@ -946,7 +962,9 @@ struct BackBlock {
 // Solves the NV*16 system held in G (ridge not yet added).  xc[k] of lane (.,q) is the solution
 // component of dimension q*NV + k.  Returns false when a pivot is not positive or the result is
 // not finite.
-template <int NV>
+// DUAL: the unknowns are the neighbours of a short row (block a = neighbours 16a .. 16a+15, the
+// first `rank` of them real) instead of the factor dimensions.
+template <int NV, bool DUAL = false>
 __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int rank, float ridge,
                                             float (&xc)[NV], float *stash = nullptr) {
     // The lane-dependent constants below are cheap to derive; hiding the lane id from the
@@ -961,7 +979,10 @@ __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int ra
     L.addr_row = 4 * L.q;          // + 64*gp: lane (gp, q)
     L.addr_col = 4 * L.irow;       // + 64*gp: lane (gp, irow)
     L.last_col = L.q == 15;
-    add_ridge<float, NV>(G, lane, rank, ridge);
+    if constexpr (DUAL)
+        add_ridge_dual<NV>(G, lane, rank, ridge);
+    else
+        add_ridge<float, NV>(G, lane, rank, ridge);
     float y[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) y[e] = col_allreduce(G.b[e]);
@@ -1042,7 +1063,7 @@ struct SolveArgs {
     const int32_t *order;       // [n_tasks] row ids, longest first
     const int32_t *slab_first;  // [n_tasks] first workspace slab of the row, -1 = short row
     const int32_t *slab_count;  // [n_tasks]
-    int n_tasks;
+    int t_begin, t_end;  // the kernel's share of the degree-sorted task list
     const int64_t *indptr;
     const int32_t *indices;
     const T *vals;
@@ -1060,6 +1081,10 @@ struct SolveArgs {
     const T *cur;      // table the rows' current vectors are read from (may be dst)
     double *err_part;  // [waves of the grid]
 };
+
+// Rows of at most this many entries are solved in the neighbour-by-neighbour ("dual") form
+// when the padded rank is larger (fp32, padded rank 128).
+constexpr int DUAL_MAX_DEG = 64;
 
 // LDS elements one wave needs: the small transposition stage on the fast path (padded rank
 // <= 64, no dump), the whole matrix otherwise.
@@ -1109,7 +1134,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
     double *lane_err_slot =
         reinterpret_cast<double *>(Asm + WaveLds<T, KP, DUMP>::ERR_AT) + lane;
     if constexpr (ERR) *lane_err_slot = 0.0;
-    for (int t = blockIdx.x * WPB + wl; t < p.n_tasks; t += W) {
+    for (int t = p.t_begin + blockIdx.x * WPB + wl; t < p.t_end; t += W) {
         const int row = p.order[t];
         const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
         T *out = p.dst + (int64_t)row * KP;
@@ -1206,6 +1231,171 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
     }
 }
 
+// ---- kernel 2b: short rows in the neighbour-by-neighbour ("dual") form ---------------------
+// A row with n stored entries, n well below the padded rank, has
+//     x = (F^T F + c I)^-1 F^T r = F^T (F F^T + c I)^-1 r,     F = [n x KP] its neighbours' rows,
+// so the n x n matrix K = F F^T replaces the KP x KP one: at padded rank 128 and n <= 64 the
+// factorisation is 8 times cheaper (64 times at n <= 32) and — unlike F^T F — K is a product
+// whose contraction runs along the factor dimension, the direction that is contiguous in
+// memory: a lane's 32-byte load (8 dimensions of one neighbour) is one matrix-core operand
+// as it stands (lane (g,q): neighbour 16a+q, dimensions 32c+8g .. +7 of chunk c), nothing is
+// transposed.  The products again go through the scaled two-way fp16 split.  Afterwards
+// w = (K + c I)^-1 r is formed by the same block solver (unknowns = neighbours; rows of K
+// beyond n are zero, get a unit diagonal and a zero right-hand side) and x = F^T w re-reads
+// the neighbours' rows, which the wave has just touched.
+// ERR: the squared error of the row's current vector needs <u, f_t> per neighbour, which is
+// a by-product of the first pass here (the fp32 rows are in registers), so it is summed
+// directly instead of through the quadratic form the KP x KP kernel uses.
+// Waves per SIMD the dual kernels are compiled for: all loads of a row are in flight at once,
+// which at 64 neighbours needs the registers of two waves per SIMD.
+#ifndef DUAL64_MIN_WAVES
+#define DUAL64_MIN_WAVES 2
+#endif
+#ifndef DUAL32_MIN_WAVES
+#define DUAL32_MIN_WAVES 4
+#endif
+template <int NV, int ND, bool ERR>
+__global__ __launch_bounds__(256, (ND > 2 ? DUAL64_MIN_WAVES : DUAL32_MIN_WAVES)) void solve_rows_dual_kernel(SolveArgs<float> p) {
+    constexpr int KP = NV * 16;
+    constexpr int NC = KP / 32;  // 32-dimension chunks, one matrix instruction deep each
+    static_assert(KP % 32 == 0 && ND * 16 <= WAVE, "one index block per row");
+    const int lane = threadIdx.x & 63;
+    const int wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = gridDim.x * 4;
+    const float scale = split_scale(p.max_bits[0]);
+    const float s2 = scale * scale;
+    double err_acc = 0.0;
+    for (int t = p.t_begin + blockIdx.x * 4 + wl; t < p.t_end; t += W) {
+        const int row = p.order[t];
+        const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
+        const int n = (int)(end - beg);
+        float *out = p.dst + (int64_t)row * KP;
+        if (n <= 0) {
+#pragma unroll
+            for (int rr = 0; rr < KP / 64; ++rr) out[lane + 64 * rr] = 0.0f;
+            continue;
+        }
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));  // lane constants derived per row, not kept across rows
+        const int g = lane_v >> 4, q = lane_v & 15;
+        // lanes past the row's end repeat its first entry (their rows of F are zeroed below; the
+        // address stays one the row really reads)
+        const int64_t at = beg + (lane_v < n ? lane_v : 0);
+        const int idx = p.indices[at];
+        const float rv = lane_v < n ? p.vals[at] : 0.0f;
+        int id[ND];
+        bool real[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            id[a] = __builtin_amdgcn_ds_bpermute(4 * (16 * a + q), idx);
+            real[a] = 16 * a + q < n;
+        }
+        const float *srcg = p.src + 8 * g;
+        Gram<float, ND> G;
+        G.zero();
+        float pred[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) pred[a] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float v[ND][8];
+#pragma unroll
+            for (int a = 0; a < ND; ++a)
+                load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
+            if constexpr (ERR) {
+                float uc[8];
+                load_vec<float, 8>(uc, p.cur + ((int64_t)row * KP + 32 * c) + 8 * g);
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pred[a] += v[a][j] * uc[j];
+            }
+            f16x8 H[ND], L[ND];
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    f32x2 x = f32x2{v[a][j], v[a][j + 1]} * scale;
+                    x = real[a] ? x : f32x2{0.0f, 0.0f};
+                    const f16x2 h = __builtin_convertvector(x, f16x2);
+                    const f32x2 rest = x - __builtin_convertvector(h, f32x2);  // exact
+                    const f16x2 l = __builtin_convertvector(rest, f16x2);
+                    H[a][j] = h[0];
+                    H[a][j + 1] = h[1];
+                    L[a][j] = l[0];
+                    L[a][j + 1] = l[1];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < ND; ++a)
+#pragma unroll
+                for (int b = a; b < ND; ++b) {
+                    Mfma<float>::acc_t acc = G.acc[tri_index(a, b, ND)];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(H[a], L[b], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(L[a], H[b], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(H[a], H[b], acc, 0, 0, 0);
+                    G.acc[tri_index(a, b, ND)] = acc;
+                }
+        }
+        // right-hand side S^2 r, one neighbour per column; block_solve adds the four lane groups
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            const float ra = bperm(4 * (16 * a + q), rv);
+            G.b[a] = g == 0 ? ra * s2 : 0.0f;
+            if constexpr (ERR) {
+                const float pa = col_allreduce(pred[a]);
+                const double e = (double)ra - (double)pa;
+                err_acc += (g == 0 && real[a]) ? e * e : 0.0;
+            }
+        }
+        float w[ND];
+        const bool ok = block_solve<ND, true>(G, lane, n, p.alpha * (float)n * s2, w);
+        // x = F^T w: this lane's neighbours again, 8 dimensions of each chunk; then the sum
+        // over the 16 lanes of a lane group
+        float xp[NC][8];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float v[ND][8];
+#pragma unroll
+            for (int a = 0; a < ND; ++a)
+                load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc += (real[a] ? v[a][j] : 0.0f) * w[a];
+                xp[c][j] = acc;
+            }
+        }
+        float mine[8];  // lane (g, q = c) writes dimensions 32c + 8g .. + 7
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mine[j] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sum = row_allreduce(xp[c][j]);
+                mine[j] = q == c ? sum : mine[j];
+            }
+        if (q < NC) {
+            typedef float vec_t __attribute__((ext_vector_type(4)));
+            vec_t lo, hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = ok ? mine[j] : 0.0f;
+                hi[j] = ok ? mine[4 + j] : 0.0f;
+            }
+            float *o = out + 32 * q + 8 * g;
+            *reinterpret_cast<vec_t *>(o) = lo;
+            *reinterpret_cast<vec_t *>(o + 4) = hi;
+        }
+    }
+    if constexpr (ERR) {
+        const double wave_err = wave_sum(err_acc);
+        if (lane == 0) p.err_part[blockIdx.x * 4 + wl] = wave_err;
+    }
+}
+
 }  // namespace alsmi
 
 // ---- plan ------------------------------------------------------------------------------------
@@ -1214,6 +1404,9 @@ struct alsmi_plan {
     int dtype, rank, kp, chunk, device, cu_count;
     int64_t n_rows_total, row_begin, row_end;
     int n_tasks, n_chunks, n_heavy;
+    // Tasks [t_dual64, t_dual32) have at most 64 entries, tasks [t_dual32, n_tasks) at most 32
+    // (both = n_tasks when the dual form does not apply to the plan).
+    int t_dual64, t_dual32;
     int32_t *order, *slab_first, *slab_count;
     int64_t *ch_beg, *ch_end;
     void *slabs;
@@ -1236,17 +1429,42 @@ static int ablation() {
     return v;
 }
 
+// Switches read once from the environment (diagnostics; results stay within the same
+// tolerances): ALSMI_DUAL=0 sends short rows through the KP x KP form as well.
+static bool dual_enabled() {
+    static const bool v = !(getenv("ALSMI_DUAL") && atoi(getenv("ALSMI_DUAL")) == 0);
+    return v;
+}
+
+// Grid for a kernel whose waves take tasks round-robin: every wave resident at once.
+static int resident_grid(const alsmi_plan *pl, const void *kern, int threads, size_t lds,
+                         int n_tasks, int wpb, int *grid_out) {
+    int bpc = 0;
+    ALSMI_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kern, threads, lds));
+    if (bpc < 1) bpc = 1;
+    int grid = pl->cu_count * bpc;
+    const int need = (n_tasks + wpb - 1) / wpb;
+    if (grid > need) grid = need;
+    *grid_out = grid;
+    return ALSMI_OK;
+}
+
+// Launches the KP x KP kernel on tasks [a.t_begin, a.t_end).  With want_err the kernel's
+// per-wave squared-error partials go to a.err_part[0 .. *n_err).
 template <typename T, int NV, int WPB>
-static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, double *err_out,
-                        hipStream_t st) {
+static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, bool want_err,
+                        int *n_err, hipStream_t st) {
     constexpr int KP = NV * 16;
+    *n_err = 0;
+    const int n_tasks = a.t_end - a.t_begin;
+    if (n_tasks <= 0) return ALSMI_OK;
     const size_t lds =
         (dump ? WaveLds<T, KP, true>::BYTES : WaveLds<T, KP, false>::BYTES) * WPB;
     auto kern = dump ? solve_rows_kernel<T, NV, WPB, true> : solve_rows_kernel<T, NV, WPB, false>;
-    if (err_out) kern = solve_rows_kernel<T, NV, WPB, false, 0, true>;
+    if (want_err) kern = solve_rows_kernel<T, NV, WPB, false, 0, true>;
     if constexpr (sizeof(T) == 4 && NV == 4) {
         const int ablate = ablation();
-        if (!dump && !err_out) {
+        if (!dump && !want_err) {
             if (ablate == 1) kern = solve_rows_kernel<T, NV, WPB, false, 1>;
             if (ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
             if (ablate == 4) kern = solve_rows_kernel<T, NV, WPB, false, 4>;
@@ -1259,22 +1477,35 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, double 
     // load only if every wave of the grid is resident at once: size the grid to what the
     // registers and the LDS of this instantiation admit per CU.  (Waves never wait on each
     // other, so an over-estimate costs time, not correctness.)
-    int bpc = 0;
-    ALSMI_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &bpc, reinterpret_cast<const void *>(kern), WPB * 64, lds));
-    if (bpc < 1) bpc = 1;
-    int grid = pl->cu_count * bpc;
-    const int need = (pl->n_tasks + WPB - 1) / WPB;
-    if (grid > need) grid = need;
-    if (err_out && grid * WPB > pl->err_part_cap) grid = pl->err_part_cap / WPB;
+    int grid = 0;
+    int rc = resident_grid(pl, reinterpret_cast<const void *>(kern), WPB * 64, lds, n_tasks, WPB,
+                           &grid);
+    if (rc != ALSMI_OK) return rc;
+    if (want_err && grid * WPB > pl->err_part_cap) grid = pl->err_part_cap / WPB;
     if (grid < 1) return ALSMI_OK;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), lds, st, a);
     ALSMI_HIP_CHECK(hipGetLastError());
-    if (err_out) {
-        hipLaunchKernelGGL(sum_err_kernel, dim3(1), dim3(256), 0, st, pl->err_part, grid * WPB,
-                           err_out);
-        ALSMI_HIP_CHECK(hipGetLastError());
-    }
+    if (want_err) *n_err = grid * WPB;
+    return ALSMI_OK;
+}
+
+// The dual-form kernel on tasks [a.t_begin, a.t_end), all of at most 16*ND entries.
+template <int NV, int ND>
+static int launch_dual(const alsmi_plan *pl, SolveArgs<float> a, bool want_err, int *n_err,
+                       hipStream_t st) {
+    *n_err = 0;
+    const int n_tasks = a.t_end - a.t_begin;
+    if (n_tasks <= 0) return ALSMI_OK;
+    auto kern = want_err ? solve_rows_dual_kernel<NV, ND, true>
+                         : solve_rows_dual_kernel<NV, ND, false>;
+    int grid = 0;
+    int rc = resident_grid(pl, reinterpret_cast<const void *>(kern), 256, 0, n_tasks, 4, &grid);
+    if (rc != ALSMI_OK) return rc;
+    if (want_err && grid * 4 > pl->err_part_cap) grid = pl->err_part_cap / 4;
+    if (grid < 1) return ALSMI_OK;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+    ALSMI_HIP_CHECK(hipGetLastError());
+    if (want_err) *n_err = grid * 4;
     return ALSMI_OK;
 }
 
@@ -1331,7 +1562,6 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     a.order = pl->order;
     a.slab_first = pl->slab_first;
     a.slab_count = pl->slab_count;
-    a.n_tasks = pl->n_tasks;
     a.indptr = indptr;
     a.indices = indices;
     a.vals = static_cast<const T *>(vals);
@@ -1346,7 +1576,42 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     a.row_begin = pl->row_begin;
     a.cur = static_cast<const T *>(cur);
     a.err_part = pl->err_part;
-    return launch_solve<T, NV, WPB>(pl, a, dump, err_out, st);
+    // Short rows go to the dual-form kernels (fp32, padded rank 128, not for the dump, whose
+    // output is the KP x KP system itself).  The task list is sorted by length, so each kernel
+    // takes a contiguous share; each appends its squared-error partials to the same array.
+    int t64 = pl->n_tasks, t32 = pl->n_tasks;
+    if constexpr (sizeof(T) == 4 && NV == 8) {
+        if (!dump && mode == GRAM_F16X2 && dual_enabled()) {
+            t64 = pl->t_dual64;
+            t32 = pl->t_dual32;
+        }
+    }
+    int n_err = 0, used = 0;
+    a.t_begin = 0;
+    a.t_end = t64;
+    int rc = launch_solve<T, NV, WPB>(pl, a, dump, err_out != nullptr, &used, st);
+    if (rc != ALSMI_OK) return rc;
+    n_err += used;
+    if constexpr (sizeof(T) == 4 && NV == 8) {
+        a.err_part = pl->err_part + n_err;
+        a.t_begin = t64;
+        a.t_end = t32;
+        rc = launch_dual<NV, 4>(pl, a, err_out != nullptr, &used, st);
+        if (rc != ALSMI_OK) return rc;
+        n_err += used;
+        a.err_part = pl->err_part + n_err;
+        a.t_begin = t32;
+        a.t_end = pl->n_tasks;
+        rc = launch_dual<NV, 2>(pl, a, err_out != nullptr, &used, st);
+        if (rc != ALSMI_OK) return rc;
+        n_err += used;
+    }
+    if (err_out) {
+        hipLaunchKernelGGL(sum_err_kernel, dim3(1), dim3(256), 0, st, pl->err_part, n_err,
+                           err_out);
+        ALSMI_HIP_CHECK(hipGetLastError());
+    }
+    return ALSMI_OK;
 }
 
 static int dispatch(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
@@ -1443,6 +1708,16 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     pl->n_tasks = (int)n;
     pl->n_chunks = (int)ch_beg.size();
     pl->n_heavy = n_heavy;
+    pl->t_dual64 = pl->t_dual32 = (int)n;
+    if (dtype == ALSMI_F32 && kp == 128) {
+        auto first_at_most = [&](int64_t deg) {
+            return (int)(std::partition_point(order.begin(), order.end(), [&](int32_t r) {
+                             return indptr_host[r + 1] - indptr_host[r] > deg;
+                         }) - order.begin());
+        };
+        pl->t_dual64 = first_at_most(alsmi::DUAL_MAX_DEG);
+        pl->t_dual32 = first_at_most(alsmi::DUAL_MAX_DEG / 2);
+    }
     pl->cu_count = device_cu_count();
     const size_t esz = dtype == ALSMI_F32 ? 4 : 8;
     pl->slab_bytes = (size_t)pl->n_chunks * slab_slots(kp) * esz;
@@ -1463,7 +1738,8 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     if (e == hipSuccess) e = upload((void **)&pl->max_bits, nullptr, sizeof(unsigned));
     pl->err_part_cap = pl->cu_count * 64;
     if (e == hipSuccess)
-        e = upload((void **)&pl->err_part, nullptr, (size_t)pl->err_part_cap * sizeof(double));
+        e = upload((void **)&pl->err_part, nullptr,
+                   3 * (size_t)pl->err_part_cap * sizeof(double));  // up to three kernels per call
     if (e != hipSuccess) {
         set_error("alsmi_plan_create: device allocation failed: %s", hipGetErrorString(e));
         alsmi_plan_destroy(pl);

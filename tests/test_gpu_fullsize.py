@@ -119,3 +119,71 @@ def test_whole_matrix_properties_fp32(problem):
         res = S.T.dot(S.dot(U[r])) + 0.1 * (hi - lo) * U[r] - b
         worst = max(worst, np.linalg.norm(res) / max(np.linalg.norm(b), 1e-30))
     assert worst < 2e-5
+
+
+# ---- one GPU's share of the 1 B-entry rank-128 configuration -------------------------------
+# 1.25 M users x 1 M items, 125 M entries, rank 128 (BASELINE config 4 cut over 8 GPUs), fp32.
+# Most rows here are shorter than the rank and take the neighbour-by-neighbour kernels (<= 32
+# and <= 64 entries); the popular items are cut into chunks.  The sample covers all of them.
+S_USERS, S_ITEMS, S_NNZ, S_RANK = 1250000, 1000000, 125000000, 128
+
+
+def device_rows(csr, rows):
+    """(indptr, indices, vals) of the given rows only, copied from device tensors."""
+    import torch
+    indptr, indices, vals = csr
+    ptr_h = indptr.cpu().numpy()
+    out = []
+    for r in rows:
+        lo, hi = int(ptr_h[r]), int(ptr_h[r + 1])
+        out.append((indices[lo:hi].cpu().numpy(), vals[lo:hi].to(torch.float64).cpu().numpy()))
+    return ptr_h, out
+
+
+def test_rank128_slice_sampled_rows_match_oracle():
+    import torch
+    from alsmi import device as dev
+    from alsmi import synth
+    from alsmi.engine import AlsEngine
+    from oracle import c_oracle as co
+    device = dev.require_gpu()
+    P = synth.sharded_problem(20242, S_USERS, S_ITEMS, S_NNZ, 1, 0, device)
+    eng = AlsEngine(P['csr'], P['csc'], P['shape'], S_RANK, 0.1, dtype='float32')
+    assert eng.plan_i.info()['n_chunks'] > 100
+    g = torch.Generator(device=device)
+    g.manual_seed(42)
+    eng.V[:, :S_RANK] = torch.rand((S_ITEMS, S_RANK), generator=g, device=device)
+    eng.V[:, 0] = 3.5
+    Vq = eng.V[:, :S_RANK].to(torch.float64).cpu().numpy()
+
+    def check(side_csr, table, src64, seed):
+        ptr_h, _ = device_rows(side_csr, [])
+        rows, deg = sample_rows(ptr_h, 200, seed)
+        _, data = device_rows(side_csr, rows)
+        got = table[torch.from_numpy(rows).to(device)][:, :S_RANK].to(torch.float64).cpu().numpy()
+        want = np.zeros_like(got)
+        for k, (idx, val) in enumerate(data):
+            want[k] = co.half_sweep(np.array([0, idx.size], dtype=np.int64), idx, val, src64, 0.1,
+                                    threads=1)[0]
+        err = row_rel_err(got, want)
+        d = deg[rows]
+        # every kernel is in the sample: <= 32 and <= 64 entries (neighbour form), up to one
+        # chunk (rank form) and the chunked rows
+        for lo, hi in ((1, 32), (33, 64), (65, 2048)):
+            assert ((d >= lo) & (d <= hi)).any(), (lo, hi)
+        assert err.max() < 1e-4, (err.max(), d[np.argmax(err)])
+        return d
+
+    eng.half_sweep_users()
+    d = check(P['csr'], eng.U, Vq, 3)
+    U64 = eng.U[:, :S_RANK].to(torch.float64).cpu().numpy()
+    eng.half_sweep_items()
+    d = check(P['csc'], eng.V, U64, 4)
+    assert d.max() > 4096
+    del U64, Vq
+    # the error the next user half derives for the factors it replaces against the standalone
+    # pass over all 125 M entries (1e-5 on the RMSE), and pad columns stay zero
+    rmse = eng.train_rmse()
+    fused = float(np.sqrt(float(eng.half_sweep_users_err().cpu()[0]) / eng.nnz))
+    assert abs(fused - rmse) <= 1e-5 * rmse, (fused, rmse)
+    assert torch.isfinite(eng.U).all() and torch.isfinite(eng.V).all()
