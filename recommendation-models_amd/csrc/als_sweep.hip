@@ -316,33 +316,71 @@ __device__ __forceinline__ float split_scale(unsigned max_bits) {
     return __builtin_bit_cast(float, (unsigned)(127 + 13 - e) << 23);
 }
 
-template <int NV, bool FULL, bool ERR>
-__device__ __forceinline__ void gram_block32_f16(Gram<float, NV> &G, ErrAcc<float, NV, ERR> &E,
-                                                 const float *__restrict__ src, unsigned qoff,
-                                                 int idx, float rv, int off, int valid, int g,
-                                                 float scale) {
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// One block of 4*J neighbours (J per lane group): J = 8 feeds v_mfma_f32_16x16x32_f16, J = 4
+// the half-depth v_mfma_f32_16x16x16_f16 (half the operand registers per block; what padded
+// rank 128 needs to run two waves per SIMD beside its 36 accumulator tiles).
+template <int J>
+struct F16Op;
+template <>
+struct F16Op<8> {
+    typedef f16x8 vec_t;
+    static __device__ __forceinline__ Mfma<float>::acc_t mma(vec_t a, vec_t b,
+                                                             Mfma<float>::acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct F16Op<4> {
+    typedef f16x4 vec_t;
+    static __device__ __forceinline__ Mfma<float>::acc_t mma(vec_t a, vec_t b,
+                                                             Mfma<float>::acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// 4*J neighbours at entries off .. off+4J-1 of the wave's 64-entry index block; `valid` of
+// them exist.  FULL = 1: all of them (known at compile time), 0: fewer, 2: decided at run time
+// by a branch around the masking alone, so that the matrix instructions exist once (two copies
+// of them meet in a copy of all accumulators, which two waves per SIMD have no registers for).
+template <int NV, int J, int FULL, bool ERR>
+__device__ __forceinline__ void gram_block_f16(Gram<float, NV> &G, ErrAcc<float, NV, ERR> &E,
+                                               const float *__restrict__ src, unsigned qoff,
+                                               int idx, float rv, int off, int valid, int g,
+                                               float scale) {
     constexpr int KP = NV * 16;
-    float v[8][NV];
-    float r[8];
-    // ds_bpermute byte address of lane 8g; the constant part of each neighbour's lane goes
-    // into the instruction's offset field, so one register serves all sixteen fetches
-    const int lane8g = 32 * g;
+    float v[J][NV];
+    float r[J];
+    // ds_bpermute byte address of lane J*g; the constant part of each neighbour's lane goes
+    // into the instruction's offset field, so one register serves all fetches
+    const int lane_jg = 4 * J * g;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int t = 8 * g + j;
-        const unsigned id = (unsigned)__builtin_amdgcn_ds_bpermute(lane8g + 4 * (off + j), idx);
-        r[j] = bperm(lane8g + 4 * (off + j), rv);
+    for (int j = 0; j < J; ++j) {
+        const int t = J * g + j;
+        const unsigned id = (unsigned)__builtin_amdgcn_ds_bpermute(lane_jg + 4 * (off + j), idx);
+        r[j] = bperm(lane_jg + 4 * (off + j), rv);
         // uniform base + 32-bit byte offset (the host checks that the table is below 4 GiB)
         load_vec<float, NV>(v[j], reinterpret_cast<const float *>(
                                       reinterpret_cast<const char *>(src) + (id * (KP * 4u) + qoff)));
-        if constexpr (!FULL) {
+        if constexpr (FULL == 0) {
             const bool ok = t < valid;
 #pragma unroll
             for (int e = 0; e < NV; ++e) v[j][e] = ok ? v[j][e] : 0.0f;
         }
     }
+    if constexpr (FULL == 2) {
+        if (valid < 4 * J) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < J; ++j) {
+                const bool ok = J * g + j < valid;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[j][e] = ok ? v[j][e] : 0.0f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) G.b[e] += r[j] * v[j][e];
     }
@@ -350,9 +388,9 @@ __device__ __forceinline__ void gram_block32_f16(Gram<float, NV> &G, ErrAcc<floa
     // of one neighbour); the fp16 packs join two neighbours of one dimension, which the
     // conversion instructions take from any two registers.  Two neighbours at a time, so
     // that few temporaries are live.
-    f16x8 H[NV], L[NV];
+    typename F16Op<J>::vec_t H[NV], L[NV];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < J / 2; ++i) {
         float xs[2][NV], hf[2][NV];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -401,12 +439,22 @@ __device__ __forceinline__ void gram_block32_f16(Gram<float, NV> &G, ErrAcc<floa
 #pragma unroll
         for (int f = e; f < NV; ++f) {
             Mfma<float>::acc_t c = G.acc[tri_index(e, f, NV)];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H[e], L[f], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(L[e], H[f], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H[e], H[f], c, 0, 0, 0);
+            c = F16Op<J>::mma(H[e], L[f], c);
+            c = F16Op<J>::mma(L[e], H[f], c);
+            c = F16Op<J>::mma(H[e], H[f], c);
             G.acc[tri_index(e, f, NV)] = c;
         }
 }
+
+// Waves per SIMD the fp32 rank-64 kernels are compiled for (register budget 512 / waves).
+#ifndef SOLVE_MIN_WAVES
+#define SOLVE_MIN_WAVES 3
+#endif
+// Padded rank 128 (fp32): two waves per SIMD beside the 36 accumulator tiles, which the Gram
+// build pays for with half-depth matrix instructions (16 neighbours per block).
+#ifndef R128_MIN_WAVES
+#define R128_MIN_WAVES 2
+#endif
 
 // How an instantiation builds the Gram matrix.
 enum { GRAM_NATIVE = 0,  // the MFMA of the data type (fp64; fp32 at padded rank 128)
@@ -428,14 +476,18 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
         idx_n = indices[beg + lane];
         rv_n = vals[beg + lane];
     }
+    // neighbours per lane group and block: 8 (the full-depth instruction) except at padded rank
+    // 128 compiled for two waves per SIMD, where the operand registers of a block must halve
+    constexpr int J = (NV == 8 && R128_MIN_WAVES >= 2) ? 4 : 8;
     auto block = [&](auto full, int idx, float rv, int off, int valid) {
         constexpr bool FULL = decltype(full)::value;
         if constexpr (MODE == GRAM_F16X2)
-            gram_block32_f16<NV, FULL, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv, off, valid,
-                                            g, scale);
+            gram_block_f16<NV, J, FULL ? 1 : 0, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv,
+                                                     off, valid, g, scale);
         else
             gram_block32_split<NV, FULL, ERR>(G, E, srcq, idx, rv, off, valid, g);
     };
+    constexpr int BLK = MODE == GRAM_F16X2 ? 4 * J : 32;  // neighbours per block
     for (int64_t base = beg; base < end; base += WAVE) {
         const int64_t left = end - base;
         const int cnt = left < WAVE ? (int)left : WAVE;
@@ -448,14 +500,20 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
             idx_n = indices[base + WAVE + lane];
             rv_n = vals[base + WAVE + lane];
         }
-        if (cnt >= 32)
-            block(std::true_type{}, idx, rv, 0, 32);
-        else
-            block(std::false_type{}, idx, rv, 0, cnt);
-        if (cnt == 64)
-            block(std::true_type{}, idx, rv, 32, 32);
-        else if (cnt > 32)
-            block(std::false_type{}, idx, rv, 32, cnt - 32);
+        if constexpr (J == 4 && MODE == GRAM_F16X2) {
+#pragma unroll 1
+            for (int off = 0; off < cnt; off += BLK)
+                gram_block_f16<NV, J, 2, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv, off,
+                                              cnt - off, g, scale);
+        } else {
+#pragma unroll
+            for (int off = 0; off < WAVE; off += BLK) {
+                if (cnt >= off + BLK)
+                    block(std::true_type{}, idx, rv, off, BLK);
+                else if (cnt > off)
+                    block(std::false_type{}, idx, rv, off, cnt - off);
+            }
+        }
     }
 }
 
@@ -512,13 +570,6 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const float *__restrict__ 
                            unsigned, fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 
-// Waves per SIMD the fp32 rank-64 kernels are compiled for (register budget 512 / waves).
-#ifndef SOLVE_MIN_WAVES
-#define SOLVE_MIN_WAVES 3
-#endif
-#ifndef R128_MIN_WAVES
-#define R128_MIN_WAVES 1
-#endif
 
 // ---- kernel 1: partial normal equations of the chunks of long rows ---------------------
 // ERR: also the chunk's sum of squared ratings (last slab slot).
@@ -801,6 +852,12 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
     const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
     return v + __builtin_bit_cast(float, t);
+}
+// the value of another lane of the row (DPP control CTRL)
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
 // sum over the 16 lanes of a row, result in each of them
 __device__ __forceinline__ float row_allreduce(float v) {
@@ -1244,8 +1301,9 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
 // beyond n are zero, get a unit diagonal and a zero right-hand side) and x = F^T w re-reads
 // the neighbours' rows, which the wave has just touched.
 // ERR: the squared error of the row's current vector needs <u, f_t> per neighbour, which is
-// a by-product of the first pass here (the fp32 rows are in registers), so it is summed
-// directly instead of through the quadratic form the KP x KP kernel uses.
+// a by-product of the second pass here (the fp32 rows are in registers and the accumulator
+// tiles are dead), so it is summed directly instead of through the quadratic form the
+// KP x KP kernel uses.
 // Waves per SIMD the dual kernels are compiled for: all loads of a row are in flight at once,
 // which at 64 neighbours needs the registers of two waves per SIMD.
 #ifndef DUAL64_MIN_WAVES
@@ -1255,7 +1313,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
 #define DUAL32_MIN_WAVES 4
 #endif
 template <int NV, int ND, bool ERR>
-__global__ __launch_bounds__(256, (ND > 2 ? DUAL64_MIN_WAVES : DUAL32_MIN_WAVES)) void solve_rows_dual_kernel(SolveArgs<float> p) {
+__global__ __launch_bounds__(256, (ND > 3 ? DUAL64_MIN_WAVES : (ND > 2 ? 3 : DUAL32_MIN_WAVES))) void solve_rows_dual_kernel(SolveArgs<float> p) {
     constexpr int KP = NV * 16;
     constexpr int NC = KP / 32;  // 32-dimension chunks, one matrix instruction deep each
     static_assert(KP % 32 == 0 && ND * 16 <= WAVE, "one index block per row");
@@ -1302,21 +1360,16 @@ __global__ __launch_bounds__(256, (ND > 2 ? DUAL64_MIN_WAVES : DUAL32_MIN_WAVES)
 #pragma unroll
             for (int a = 0; a < ND; ++a)
                 load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
-            if constexpr (ERR) {
-                float uc[8];
-                load_vec<float, 8>(uc, p.cur + ((int64_t)row * KP + 32 * c) + 8 * g);
-#pragma unroll
-                for (int a = 0; a < ND; ++a)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pred[a] += v[a][j] * uc[j];
-            }
             f16x8 H[ND], L[ND];
 #pragma unroll
             for (int a = 0; a < ND; ++a) {
+                // instantiation ND only sees rows of more than 16 (ND - 1) entries (shorter ones
+                // go to a smaller one), so all its tiles but the last are full
+                const bool maybe_partial = a == ND - 1;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
                     f32x2 x = f32x2{v[a][j], v[a][j + 1]} * scale;
-                    x = real[a] ? x : f32x2{0.0f, 0.0f};
+                    if (maybe_partial) x = real[a] ? x : f32x2{0.0f, 0.0f};
                     const f16x2 h = __builtin_convertvector(x, f16x2);
                     const f32x2 rest = x - __builtin_convertvector(h, f32x2);  // exact
                     const f16x2 l = __builtin_convertvector(rest, f16x2);
@@ -1342,17 +1395,18 @@ __global__ __launch_bounds__(256, (ND > 2 ? DUAL64_MIN_WAVES : DUAL32_MIN_WAVES)
         for (int a = 0; a < ND; ++a) {
             const float ra = bperm(4 * (16 * a + q), rv);
             G.b[a] = g == 0 ? ra * s2 : 0.0f;
-            if constexpr (ERR) {
-                const float pa = col_allreduce(pred[a]);
-                const double e = (double)ra - (double)pa;
-                err_acc += (g == 0 && real[a]) ? e * e : 0.0;
-            }
         }
         float w[ND];
         const bool ok = block_solve<ND, true>(G, lane, n, p.alpha * (float)n * s2, w);
-        // x = F^T w: this lane's neighbours again, 8 dimensions of each chunk; then the sum
-        // over the 16 lanes of a lane group
+        // x = F^T w: this lane's neighbours again (a lane past the row's end re-reads the
+        // row's first neighbour with a zero weight), 8 dimensions of each chunk; then the sum
+        // over the 16 lanes of a lane group, as a reduce-scatter: after the exchanges over
+        // lane bits 3 and 2 a lane keeps one chunk, after bits 1 and 0 two dimensions of it.
         float xp[NC][8];
+        // (the optimiser must not keep the first pass's 128 loaded registers alive through the
+        // solve in order to skip these loads)
+#pragma unroll
+        for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(id[a]));
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             float v[ND][8];
@@ -1363,31 +1417,92 @@ __global__ __launch_bounds__(256, (ND > 2 ? DUAL64_MIN_WAVES : DUAL32_MIN_WAVES)
             for (int j = 0; j < 8; ++j) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int a = 0; a < ND; ++a) acc += (real[a] ? v[a][j] : 0.0f) * w[a];
+                for (int a = 0; a < ND; ++a) acc += v[a][j] * (ok ? w[a] : 0.0f);
                 xp[c][j] = acc;
             }
         }
-        float mine[8];  // lane (g, q = c) writes dimensions 32c + 8g .. + 7
+        static_assert(NC == 4 || NC == 2, "chunks per row");
+        const bool b3 = q & 8, b2 = q & 4, b1 = q & 2, b0 = q & 1;
+        float s8[8], s4[4], s2[2];
+        if constexpr (NC == 4) {
+            float h[2][8];  // chunks {0,1} stay with b3 = 0, chunks {2,3} with b3 = 1
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mine[j] = 0.0f;
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+                for (int j = 0; j < 8; ++j) {
+                    const float keep = b3 ? xp[c + 2][j] : xp[c][j];
+                    const float give = b3 ? xp[c][j] : xp[c + 2][j];
+                    h[c][j] = keep + dpp_get<0x128>(give);  // row_ror:8 = lane q ^ 8
+                }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float sum = row_allreduce(xp[c][j]);
-                mine[j] = q == c ? sum : mine[j];
+                const float keep = b2 ? h[1][j] : h[0][j];
+                const float give = b2 ? h[0][j] : h[1][j];
+                // lane q ^ 4: rotate by 4 towards the partner, either direction by lane
+                // (both fetched by every lane: a fetch inside a branch would read lanes the
+                // branch has switched off)
+                const float below = dpp_get<0x124>(give), above = dpp_get<0x12C>(give);
+                s8[j] = keep + (b2 ? below : above);
             }
-        if (q < NC) {
-            typedef float vec_t __attribute__((ext_vector_type(4)));
-            vec_t lo, hi;
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                lo[j] = ok ? mine[j] : 0.0f;
-                hi[j] = ok ? mine[4 + j] : 0.0f;
+            for (int j = 0; j < 8; ++j) {
+                const float t = xp[0][j] + dpp_get<0x128>(xp[0][j]);
+                const float u = xp[1][j] + dpp_get<0x128>(xp[1][j]);
+                const float keep = b2 ? u : t;
+                const float give = b2 ? t : u;
+                // (both fetched by every lane: a fetch inside a branch would read lanes the
+                // branch has switched off)
+                const float below = dpp_get<0x124>(give), above = dpp_get<0x12C>(give);
+                s8[j] = keep + (b2 ? below : above);
             }
-            float *o = out + 32 * q + 8 * g;
-            *reinterpret_cast<vec_t *>(o) = lo;
-            *reinterpret_cast<vec_t *>(o + 4) = hi;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float keep = b1 ? s8[4 + j] : s8[j];
+            const float give = b1 ? s8[j] : s8[4 + j];
+            s4[j] = keep + dpp_get<0x4E>(give);  // quad_perm [2,3,0,1] = lane q ^ 2
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = b0 ? s4[2 + j] : s4[j];
+            const float give = b0 ? s4[j] : s4[2 + j];
+            s2[j] = keep + dpp_get<0xB1>(give);  // quad_perm [1,0,3,2] = lane q ^ 1
+        }
+        if constexpr (ERR) {
+            // <current vector, neighbour> per neighbour, in a pass of its own over the rows
+            // (cache hits by now): inside the pass above it costs a wave per SIMD in
+            // registers.  The current vector may live in the table being written: read it
+            // before the store below.
+#pragma unroll
+            for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(id[a]));
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float v[ND][8], uc[8];
+                load_vec<float, 8>(uc, p.cur + ((int64_t)row * KP + 32 * c) + 8 * g);
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+                    load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pred[a] += v[a][j] * uc[j];
+            }
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+                const float ra = bperm(4 * (16 * a + q), rv);
+                const float pa = col_allreduce(pred[a]);
+                const double e = (double)ra - (double)pa;
+                err_acc += (g == 0 && real[a]) ? e * e : 0.0;
+            }
+        }
+        // lane q now holds dimensions 32*c + 8*g + 4*b1 + 2*b0 + {0,1} of chunk
+        // c = (NC == 4 ? 2*b3 + b2 : b2); with NC == 2 both b3 halves hold the same sums
+        {
+            const int c = NC == 4 ? ((q >> 2) & 3) : ((q >> 2) & 1);
+            f32x2 o = {s2[0], s2[1]};
+            float *dstp = out + 32 * c + 8 * g + 2 * (q & 3);
+            if (NC == 4 || !b3) *reinterpret_cast<f32x2 *>(dstp) = o;
         }
     }
     if constexpr (ERR) {
@@ -1404,9 +1519,9 @@ struct alsmi_plan {
     int dtype, rank, kp, chunk, device, cu_count;
     int64_t n_rows_total, row_begin, row_end;
     int n_tasks, n_chunks, n_heavy;
-    // Tasks [t_dual64, t_dual32) have at most 64 entries, tasks [t_dual32, n_tasks) at most 32
-    // (both = n_tasks when the dual form does not apply to the plan).
-    int t_dual64, t_dual32;
+    // Tasks [t_dual[k], t_dual[k+1]) have at most 16 (4 - k) entries (and more than 16 (3 - k));
+    // t_dual[4] = n_tasks, and all five = n_tasks when the dual form does not apply to the plan.
+    int t_dual[5];
     int32_t *order, *slab_first, *slab_count;
     int64_t *ch_beg, *ch_end;
     void *slabs;
@@ -1579,32 +1694,30 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     // Short rows go to the dual-form kernels (fp32, padded rank 128, not for the dump, whose
     // output is the KP x KP system itself).  The task list is sorted by length, so each kernel
     // takes a contiguous share; each appends its squared-error partials to the same array.
-    int t64 = pl->n_tasks, t32 = pl->n_tasks;
-    if constexpr (sizeof(T) == 4 && NV == 8) {
-        if (!dump && mode == GRAM_F16X2 && dual_enabled()) {
-            t64 = pl->t_dual64;
-            t32 = pl->t_dual32;
-        }
-    }
+    bool dual = false;
+    if constexpr (sizeof(T) == 4 && NV == 8) dual = !dump && mode == GRAM_F16X2 && dual_enabled();
     int n_err = 0, used = 0;
     a.t_begin = 0;
-    a.t_end = t64;
+    a.t_end = dual ? pl->t_dual[0] : pl->n_tasks;
     int rc = launch_solve<T, NV, WPB>(pl, a, dump, err_out != nullptr, &used, st);
     if (rc != ALSMI_OK) return rc;
     n_err += used;
     if constexpr (sizeof(T) == 4 && NV == 8) {
-        a.err_part = pl->err_part + n_err;
-        a.t_begin = t64;
-        a.t_end = t32;
-        rc = launch_dual<NV, 4>(pl, a, err_out != nullptr, &used, st);
-        if (rc != ALSMI_OK) return rc;
-        n_err += used;
-        a.err_part = pl->err_part + n_err;
-        a.t_begin = t32;
-        a.t_end = pl->n_tasks;
-        rc = launch_dual<NV, 2>(pl, a, err_out != nullptr, &used, st);
-        if (rc != ALSMI_OK) return rc;
-        n_err += used;
+        if (dual) {
+            for (int k = 0; k < 4; ++k) {
+                a.err_part = pl->err_part + n_err;
+                a.t_begin = pl->t_dual[k];
+                a.t_end = pl->t_dual[k + 1];
+                switch (k) {
+                    case 0: rc = launch_dual<NV, 4>(pl, a, err_out != nullptr, &used, st); break;
+                    case 1: rc = launch_dual<NV, 3>(pl, a, err_out != nullptr, &used, st); break;
+                    case 2: rc = launch_dual<NV, 2>(pl, a, err_out != nullptr, &used, st); break;
+                    default: rc = launch_dual<NV, 1>(pl, a, err_out != nullptr, &used, st); break;
+                }
+                if (rc != ALSMI_OK) return rc;
+                n_err += used;
+            }
+        }
     }
     if (err_out) {
         hipLaunchKernelGGL(sum_err_kernel, dim3(1), dim3(256), 0, st, pl->err_part, n_err,
@@ -1708,15 +1821,14 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     pl->n_tasks = (int)n;
     pl->n_chunks = (int)ch_beg.size();
     pl->n_heavy = n_heavy;
-    pl->t_dual64 = pl->t_dual32 = (int)n;
+    for (int k = 0; k < 5; ++k) pl->t_dual[k] = (int)n;
     if (dtype == ALSMI_F32 && kp == 128) {
-        auto first_at_most = [&](int64_t deg) {
-            return (int)(std::partition_point(order.begin(), order.end(), [&](int32_t r) {
-                             return indptr_host[r + 1] - indptr_host[r] > deg;
-                         }) - order.begin());
-        };
-        pl->t_dual64 = first_at_most(alsmi::DUAL_MAX_DEG);
-        pl->t_dual32 = first_at_most(alsmi::DUAL_MAX_DEG / 2);
+        for (int k = 0; k < 4; ++k) {
+            const int64_t deg = alsmi::DUAL_MAX_DEG - 16 * k;
+            pl->t_dual[k] = (int)(std::partition_point(order.begin(), order.end(), [&](int32_t r) {
+                                      return indptr_host[r + 1] - indptr_host[r] > deg;
+                                  }) - order.begin());
+        }
     }
     pl->cu_count = device_cu_count();
     const size_t esz = dtype == ALSMI_F32 ? 4 : 8;
@@ -1739,7 +1851,7 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     pl->err_part_cap = pl->cu_count * 64;
     if (e == hipSuccess)
         e = upload((void **)&pl->err_part, nullptr,
-                   3 * (size_t)pl->err_part_cap * sizeof(double));  // up to three kernels per call
+                   5 * (size_t)pl->err_part_cap * sizeof(double));  // up to five kernels per call
     if (e != hipSuccess) {
         set_error("alsmi_plan_create: device allocation failed: %s", hipGetErrorString(e));
         alsmi_plan_destroy(pl);
