@@ -344,7 +344,7 @@ struct F16Op<4> {
 // them exist.  FULL = 1: all of them (known at compile time), 0: fewer, 2: decided at run time
 // by a branch around the masking alone, so that the matrix instructions exist once (two copies
 // of them meet in a copy of all accumulators, which two waves per SIMD have no registers for).
-template <int NV, int J, int FULL, bool ERR>
+template <int NV, int J, int FULL, bool WIDE, bool ERR>
 __device__ __forceinline__ void gram_block_f16(Gram<float, NV> &G, ErrAcc<float, NV, ERR> &E,
                                                const float *__restrict__ src, unsigned qoff,
                                                int idx, float rv, int off, int valid, int g,
@@ -360,9 +360,17 @@ __device__ __forceinline__ void gram_block_f16(Gram<float, NV> &G, ErrAcc<float,
         const int t = J * g + j;
         const unsigned id = (unsigned)__builtin_amdgcn_ds_bpermute(lane_jg + 4 * (off + j), idx);
         r[j] = bperm(lane_jg + 4 * (off + j), rv);
-        // uniform base + 32-bit byte offset (the host checks that the table is below 4 GiB)
-        load_vec<float, NV>(v[j], reinterpret_cast<const float *>(
-                                      reinterpret_cast<const char *>(src) + (id * (KP * 4u) + qoff)));
+        if constexpr (WIDE) {
+            // 64-bit addressing: at padded rank 128 a table of 10 M rows passes 4 GiB
+            load_vec<float, NV>(v[j], reinterpret_cast<const float *>(
+                                          reinterpret_cast<const char *>(src) +
+                                          ((uint64_t)id * (KP * 4u) + qoff)));
+        } else {
+            // uniform base + 32-bit byte offset (the host checks that the table is below 4 GiB)
+            load_vec<float, NV>(v[j], reinterpret_cast<const float *>(
+                                          reinterpret_cast<const char *>(src) +
+                                          (id * (KP * 4u) + qoff)));
+        }
         if constexpr (FULL == 0) {
             const bool ok = t < valid;
 #pragma unroll
@@ -459,7 +467,11 @@ __device__ __forceinline__ void gram_block_f16(Gram<float, NV> &G, ErrAcc<float,
 // How an instantiation builds the Gram matrix.
 enum { GRAM_NATIVE = 0,  // the MFMA of the data type (fp64; fp32 at padded rank 128)
        GRAM_BF16X3 = 1,  // fp32 data, exact three-way bf16 split, unscaled accumulators
-       GRAM_F16X2 = 2 }; // fp32 data, scaled two-way fp16 split, accumulators hold S^2 G
+       GRAM_F16X2 = 2,   // fp32 data, scaled two-way fp16 split, accumulators hold S^2 G
+       GRAM_F16X2_WIDE = 3 };  // the same with 64-bit gather addresses (tables above 4 GiB)
+__host__ __device__ constexpr bool is_f16x2(int mode) {
+    return mode == GRAM_F16X2 || mode == GRAM_F16X2_WIDE;
+}
 
 // Accumulate entries [beg, end) of one row on the 16-bit matrix cores (fp32 data).
 template <int NV, int MODE, bool ERR>
@@ -481,13 +493,13 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
     constexpr int J = (NV == 8 && R128_MIN_WAVES >= 2) ? 4 : 8;
     auto block = [&](auto full, int idx, float rv, int off, int valid) {
         constexpr bool FULL = decltype(full)::value;
-        if constexpr (MODE == GRAM_F16X2)
-            gram_block_f16<NV, J, FULL ? 1 : 0, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv,
+        if constexpr (is_f16x2(MODE))
+            gram_block_f16<NV, J, FULL ? 1 : 0, MODE == GRAM_F16X2_WIDE, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv,
                                                      off, valid, g, scale);
         else
             gram_block32_split<NV, FULL, ERR>(G, E, srcq, idx, rv, off, valid, g);
     };
-    constexpr int BLK = MODE == GRAM_F16X2 ? 4 * J : 32;  // neighbours per block
+    constexpr int BLK = is_f16x2(MODE) ? 4 * J : 32;  // neighbours per block
     for (int64_t base = beg; base < end; base += WAVE) {
         const int64_t left = end - base;
         const int cnt = left < WAVE ? (int)left : WAVE;
@@ -500,10 +512,10 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
             idx_n = indices[base + WAVE + lane];
             rv_n = vals[base + WAVE + lane];
         }
-        if constexpr (J == 4 && MODE == GRAM_F16X2) {
+        if constexpr (J == 4 && is_f16x2(MODE)) {
 #pragma unroll 1
             for (int off = 0; off < cnt; off += BLK)
-                gram_block_f16<NV, J, 2, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv, off,
+                gram_block_f16<NV, J, 2, MODE == GRAM_F16X2_WIDE, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv, off,
                                               cnt - off, g, scale);
         } else {
 #pragma unroll
@@ -526,6 +538,7 @@ template <typename T, int NV, int ABLATE, bool DUMP>
 constexpr int gram_mode() {
     if (sizeof(T) != 4 || NV > 8 || ABLATE == 4) return GRAM_NATIVE;
     if (DUMP) return NV <= 4 ? GRAM_BF16X3 : GRAM_NATIVE;
+    if (ABLATE == 20) return GRAM_F16X2_WIDE;
     return ABLATE == 10 ? GRAM_BF16X3 : GRAM_F16X2;
 }
 
@@ -574,7 +587,7 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const float *__restrict__ 
 // ---- kernel 1: partial normal equations of the chunks of long rows ---------------------
 // ERR: also the chunk's sum of squared ratings (last slab slot).
 template <typename T, int NV, int MODE, bool ERR = false>
-__global__ __launch_bounds__(256, (NV == 4 ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES : 2) : (NV == 8 && sizeof(T) == 4 && MODE == GRAM_F16X2 ? R128_MIN_WAVES : 1))) void gram_chunks_kernel(
+__global__ __launch_bounds__(256, (NV == 4 ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES : 2) : (NV == 8 && sizeof(T) == 4 && is_f16x2(MODE) ? R128_MIN_WAVES : 1))) void gram_chunks_kernel(
     const int64_t *__restrict__ ch_beg, const int64_t *__restrict__ ch_end, int n_chunks,
     const int32_t *__restrict__ indices, const T *__restrict__ vals, const T *__restrict__ src,
     const unsigned *__restrict__ max_bits, T *__restrict__ slabs) {
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(256, (NV == 4 ? (sizeof(T) == 4 ? SOLVE_MIN_WAVES :
     ErrAcc<T, NV, ERR> E;
     E.init();
     float scale = 1.0f;
-    if constexpr (MODE == GRAM_F16X2) scale = split_scale(max_bits[0]);
+    if constexpr (is_f16x2(MODE)) scale = split_scale(max_bits[0]);
     gram_accumulate<T, NV, MODE, ERR>(G, E, indices, vals, src, ch_beg[w], ch_end[w], lane, scale);
     G.store(slabs + (size_t)w * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane, E.sum);
 }
@@ -1166,6 +1179,8 @@ struct WaveLds {
 // rank 64): 1 = accumulate but skip the solve, 2 = solve but skip the accumulation, 4 = Gram
 // build on the fp32 MFMA, 10 = on the bf16 matrix cores with the exact three-way split (both
 // kernels).  The production kernel is the ABLATE = 0 instantiation and contains none of that code.
+// ABLATE = 20 is not a diagnostic: it selects 64-bit gather addresses (padded rank 128, source
+// tables above 4 GiB).
 // ERR builds also sum (rating - <current vector, neighbour>)^2 over every entry they read: the
 // training error of the factors BEFORE this half-sweep, at no extra memory traffic.
 template <typename T, int NV, int WPB, bool DUMP, int ABLATE = 0, bool ERR = false>
@@ -1184,7 +1199,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
     const int W = gridDim.x * WPB;
     constexpr int MODE = gram_mode<T, NV, ABLATE, DUMP>();
     float scale = 1.0f;
-    if constexpr (MODE == GRAM_F16X2) scale = split_scale(p.max_bits[0]);
+    if constexpr (is_f16x2(MODE)) scale = split_scale(p.max_bits[0]);
     const T s2 = (T)(scale * scale), inv_s2 = (T)(1.0f / (scale * scale));
     // This lane's share of the squared error of the wave's rows lives in the wave's LDS area
     // (64 doubles behind the work area), not in two registers across the gather.
@@ -1232,7 +1247,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             __builtin_amdgcn_wave_barrier();
             *lane_err_slot += row_error_part<T, NV>(G, E.sum, Asm, lane, inv_s2);
         }
-        if constexpr (MODE == GRAM_F16X2) {  // (S^2 A) x = S^2 b
+        if constexpr (is_f16x2(MODE)) {  // (S^2 A) x = S^2 b
 #pragma unroll
             for (int e = 0; e < NV; ++e) G.b[e] *= s2;
         }
@@ -1551,6 +1566,13 @@ static bool dual_enabled() {
     return v;
 }
 
+// Does an fp32 source table of n_src rows need 64-bit gather addresses?  ALSMI_WIDE=1 forces
+// them on (test aid).
+static bool wide_table(int64_t n_src, int kp) {
+    static const bool force = getenv("ALSMI_WIDE") && atoi(getenv("ALSMI_WIDE")) != 0;
+    return force || n_src * (int64_t)kp * 4 > (int64_t)UINT32_MAX;
+}
+
 // Grid for a kernel whose waves take tasks round-robin: every wave resident at once.
 static int resident_grid(const alsmi_plan *pl, const void *kern, int threads, size_t lds,
                          int n_tasks, int wpb, int *grid_out) {
@@ -1568,7 +1590,7 @@ static int resident_grid(const alsmi_plan *pl, const void *kern, int threads, si
 // per-wave squared-error partials go to a.err_part[0 .. *n_err).
 template <typename T, int NV, int WPB>
 static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, bool want_err,
-                        int *n_err, hipStream_t st) {
+                        bool wide, int *n_err, hipStream_t st) {
     constexpr int KP = NV * 16;
     *n_err = 0;
     const int n_tasks = a.t_end - a.t_begin;
@@ -1577,6 +1599,11 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, bool wa
         (dump ? WaveLds<T, KP, true>::BYTES : WaveLds<T, KP, false>::BYTES) * WPB;
     auto kern = dump ? solve_rows_kernel<T, NV, WPB, true> : solve_rows_kernel<T, NV, WPB, false>;
     if (want_err) kern = solve_rows_kernel<T, NV, WPB, false, 0, true>;
+    if constexpr (sizeof(T) == 4 && NV == 8) {
+        if (wide && !dump)
+            kern = want_err ? solve_rows_kernel<T, NV, WPB, false, 20, true>
+                            : solve_rows_kernel<T, NV, WPB, false, 20, false>;
+    }
     if constexpr (sizeof(T) == 4 && NV == 4) {
         const int ablate = ablation();
         if (!dump && !want_err) {
@@ -1638,9 +1665,14 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
             if (!dump && !err_out && ablation() == 10) mode = GRAM_BF16X3;
         }
         if (mode == GRAM_F16X2) {
-            ALSMI_REQUIRE(n_src * (int64_t)(NV * 16) * 4 <= (int64_t)UINT32_MAX,
-                          "half-sweep: an fp32 source table of %lld rows exceeds 4 GiB",
-                          (long long)n_src);
+            if (wide_table(n_src, NV * 16)) {
+                // padded rank 128 has a build with 64-bit gather addresses (a table of 10 M
+                // rows passes 4 GiB there); the smaller ranks do not
+                ALSMI_REQUIRE(NV == 8,
+                              "half-sweep: an fp32 source table of %lld rows at padded rank %d "
+                              "exceeds 4 GiB", (long long)n_src, NV * 16);
+                mode = GRAM_F16X2_WIDE;
+            }
             // scale of the fp16 split: the largest magnitude of the source table
             ALSMI_HIP_CHECK(hipMemsetAsync(pl->max_bits, 0, sizeof(unsigned), st));
             const int64_t n4 = n_src * (int64_t)(NV * 16) / 4;
@@ -1659,6 +1691,10 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
             if (mode == GRAM_F16X2)
                 chunks = err_out ? gram_chunks_kernel<T, NV, GRAM_F16X2, true>
                                  : gram_chunks_kernel<T, NV, GRAM_F16X2, false>;
+            if constexpr (NV == 8)
+                if (mode == GRAM_F16X2_WIDE)
+                    chunks = err_out ? gram_chunks_kernel<T, NV, GRAM_F16X2_WIDE, true>
+                                     : gram_chunks_kernel<T, NV, GRAM_F16X2_WIDE, false>;
             if constexpr (NV <= 4)
                 if (mode == GRAM_BF16X3) chunks = gram_chunks_kernel<T, NV, GRAM_BF16X3, false>;
         }
@@ -1695,11 +1731,12 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     // output is the KP x KP system itself).  The task list is sorted by length, so each kernel
     // takes a contiguous share; each appends its squared-error partials to the same array.
     bool dual = false;
-    if constexpr (sizeof(T) == 4 && NV == 8) dual = !dump && mode == GRAM_F16X2 && dual_enabled();
+    if constexpr (sizeof(T) == 4 && NV == 8) dual = !dump && is_f16x2(mode) && dual_enabled();
     int n_err = 0, used = 0;
     a.t_begin = 0;
     a.t_end = dual ? pl->t_dual[0] : pl->n_tasks;
-    int rc = launch_solve<T, NV, WPB>(pl, a, dump, err_out != nullptr, &used, st);
+    int rc = launch_solve<T, NV, WPB>(pl, a, dump, err_out != nullptr, mode == GRAM_F16X2_WIDE,
+                                      &used, st);
     if (rc != ALSMI_OK) return rc;
     n_err += used;
     if constexpr (sizeof(T) == 4 && NV == 8) {

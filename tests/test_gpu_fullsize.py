@@ -187,3 +187,37 @@ def test_rank128_slice_sampled_rows_match_oracle():
     fused = float(np.sqrt(float(eng.half_sweep_users_err().cpu()[0]) / eng.nnz))
     assert abs(fused - rmse) <= 1e-5 * rmse, (fused, rmse)
     assert torch.isfinite(eng.U).all() and torch.isfinite(eng.V).all()
+
+
+def test_rank128_source_table_above_4gib():
+    """At padded rank 128 the fp32 gather addresses the source table with 64 bits: rows that
+    lie beyond the 4 GiB mark of a 4.6 GB table give the same vectors as the same rows packed
+    into a small table (all three kernels: chunked, rank form, neighbour form)."""
+    import torch
+    from alsmi import device as dev
+    from oracle import c_oracle as co
+    device = dev.require_gpu()
+    rank, kp, n_src = 128, 128, 9000000          # 9 M x 512 B = 4.6 GB
+    rng = np.random.default_rng(11)
+    degs = [5, 30, 50, 64, 100, 700, 3000]
+    used = np.unique(np.concatenate([rng.integers(8400000, n_src, 3500),     # beyond 4 GiB
+                                     rng.integers(0, n_src, 500)]))
+    rows_idx = [np.sort(rng.choice(used, d, replace=False)) for d in degs]
+    indptr = np.concatenate(([0], np.cumsum(degs))).astype(np.int64)
+    indices = np.concatenate(rows_idx).astype(np.int32)
+    vals = rng.integers(1, 6, indices.size).astype(np.float64)
+    small = rng.standard_normal((used.size, rank)).astype(np.float32)
+    table = torch.zeros((n_src, kp), dtype=torch.float32, device=device)
+    table[torch.from_numpy(used).to(device)] = torch.from_numpy(small).to(device)
+    side = dev.SparseSide(indptr, indices, vals, len(degs), n_src, 'float32', device)
+    plan = dev.SweepPlan(side, rank, chunk=1024)
+    assert plan.info()['n_chunks'] >= 3
+    out = torch.zeros((len(degs), kp), dtype=torch.float32, device=device)
+    plan.half_sweep(table, out, 0.1)
+    got = out.to(torch.float64).cpu().numpy()
+    remap = np.searchsorted(used, indices).astype(np.int32)
+    want = co.half_sweep(indptr, remap, vals, small.astype(np.float64), 0.1, threads=1)
+    assert row_rel_err(got, want).max() < 1e-4
+    plan.close()
+    del table
+    torch.cuda.empty_cache()
