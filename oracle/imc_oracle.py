@@ -121,3 +121,37 @@ def dimc_fit(x, y_, users, items, r_, shape, rank, als_alpha, imc_alpha, tol,
                                        seed=seed)
     pred = als_oracle.predict_pairs(uf, itf, users, items) + xzy
     return Z, uf, itf, -als_oracle.rmse(r_, pred), pred
+
+
+# ---- rank-constrained Z = U V^T (the HIP package's extension; NO reference counterpart:
+# the reference validates n_components and ignores it, src/imc.py:148-154).  Parity of this
+# part is UNPINNED: the restatement below is checked by finite differences only. ----------
+
+def low_rank_cost_grad(U, V, X_attrs, Y_attrs, users, items, ratings, lam):
+    """f = 0.5 (sum_e (r_e - x_u^T U V^T y_i)^2 + lam (||U||^2 + ||V||^2)) and its
+    gradients (dU, dV)."""
+    Z = U.dot(V.T)
+    preds = preds_indexed(Z, X_attrs, Y_attrs, users, items)
+    G = _xt_diag_y(X_attrs, Y_attrs, users, items, preds - ratings)
+    f = 0.5 * (np.sum((ratings - preds) ** 2) + lam * (np.sum(U * U) + np.sum(V * V)))
+    return f, G.dot(V) + lam * U, G.T.dot(U) + lam * V
+
+
+def fit_low_rank(X_attrs, Y_attrs, users, items, ratings, r, lam, Z=None):
+    """L-BFGS-B over (U, V) from the rank-r truncation of the initial Z."""
+    p, q = X_attrs.shape[1], Y_attrs.shape[1]
+    Z0 = init_z(X_attrs, Y_attrs, users, items, ratings) if Z is None else Z
+    u, s, vt = np.linalg.svd(Z0, False)
+    root = np.sqrt(s[:r])
+    x0 = np.concatenate(((u[:, :r] * root).ravel(), (vt[:r].T * root).ravel()))
+
+    def fun(a):
+        U, V = a[:p * r].reshape(p, r), a[p * r:].reshape(q, r)
+        f, gu, gv = low_rank_cost_grad(U, V, X_attrs, Y_attrs, users, items, ratings, lam)
+        return f, np.concatenate((gu.ravel(), gv.ravel()))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=RuntimeWarning)
+        res = so.minimize(fun, x0, jac=True, method='L-BFGS-B')
+    U, V = res['x'][:p * r].reshape(p, r), res['x'][p * r:].reshape(q, r)
+    return U.dot(V.T), U, V

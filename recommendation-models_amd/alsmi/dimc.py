@@ -8,20 +8,25 @@ from sklearn.base import BaseEstimator
 from sklearn.utils.validation import check_is_fitted
 
 from .als import ALS
-from .imc import IMC, problem_from_samples
+from .engine import default_group
+from .imc import IMC, ImcProblem, problem_from_samples
 from .utils import _check_x, _check_y, root_mean_squared_error
 
 
 class DirtyIMC(BaseEstimator):
     """R ~ X Z Y^T + U^T V (src/dimc.py:21-89).
 
-    X is ``(x, y_, users, items)``: per-sample user features, per-sample item
-    features and the (user, item) index of every sample, or a 4-field DataHolder.
+    X is ``(x, y_, users, items)`` or a 4-field DataHolder.  The reference's form: ``x`` and
+    ``y_`` hold one feature row per SAMPLE.  Also accepted (``feature_form``): the attribute
+    form, ``x`` one row per USER and ``y_`` one row per ITEM, indexed by ``users`` /
+    ``items`` — nothing is expanded to per-sample rows, which at 100 M samples x 256
+    attributes would be 205 GB.  ``feature_form='auto'`` takes the attribute form when the
+    row counts of ``x`` / ``y_`` differ from the sample count and equal the matrix shape.
     """
 
     def __init__(self, rank=10, n_components=None, method='Newton-CG',
                  als_alpha=0.1, imc_alpha=0.1, tol=0.1, random_state=None,
-                 n_jobs=1, verbose=0):
+                 n_jobs=1, verbose=0, feature_form='auto'):
         self.rank = rank
         self.n_components = n_components
         self.method = method
@@ -31,17 +36,39 @@ class DirtyIMC(BaseEstimator):
         self.random_state = random_state
         self.n_jobs = n_jobs
         self.verbose = verbose
+        self.feature_form = feature_form
 
     def fit(self, X, y, Z=None, shape=None):
         """src/dimc.py:91-114."""
         _, _, _ = self.fit_transform(X, y, Z=Z, shape=shape)
         return self
 
-    @staticmethod
-    def _xzy(x, y_, Z):
+    def _attribute_form(self, x, y_, users, items, shape=None):
+        """True when x / y_ hold one row per user / item rather than one per sample."""
+        if self.feature_form in ('attribute', 'sample'):
+            return self.feature_form == 'attribute'
+        if self.feature_form != 'auto':
+            raise ValueError("feature_form must be 'auto', 'sample' or 'attribute'")
+        n_s = np.asarray(users).size
+        nx, ny = np.atleast_2d(x).shape[0], np.atleast_2d(y_).shape[0]
+        if nx == n_s and ny == n_s:
+            return False  # the reference's form (also when the counts happen to coincide)
+        if shape is None:
+            shape = getattr(getattr(self, 'als', None), 'shape_', None)
+        if shape is not None and (nx, ny) != tuple(int(v) for v in shape):
+            raise ValueError('x / y_ have %d / %d rows: neither one per sample (%d) nor one '
+                             'per user / item %r' % (nx, ny, n_s, tuple(shape)))
+        return True
+
+    def _problem(self, x, y_, users, items, ratings, attribute, group=None):
+        if attribute:
+            return ImcProblem(x, y_, users, items, ratings, group=group)
+        return problem_from_samples(x, y_, ratings)
+
+    def _xzy(self, x, y_, users, items, Z, attribute):
         """x_e^T Z y_e per sample (src/dimc.py:156-157, :184) on the device."""
-        prob = problem_from_samples(x, y_, np.zeros(np.atleast_2d(x).shape[0]))
-        return prob.predict_samples(Z)
+        n_s = np.asarray(users).size
+        return self._problem(x, y_, users, items, np.zeros(n_s), attribute).predict_samples(Z)
 
     def fit_transform(self, X, y, Z=None, shape=None):
         """Fit IMC, then ALS on what IMC leaves unexplained; returns
@@ -56,11 +83,14 @@ class DirtyIMC(BaseEstimator):
             raise ValueError('When y is a scalar or 1-D array shape must be' +
                              'provided.')
         r_ = _check_y(y, users, items)
-        self.imc.fit((x, y_), r_, Z=Z)
-        xzy = self._xzy(x, y_, self.imc.Z)
         if not shape:
             shape = y.shape
+        attribute = self._attribute_form(x, y_, users, items, shape)
+        prob = self._problem(x, y_, users, items, r_, attribute, group=default_group())
+        self.imc._fit_on(prob, Z)
+        xzy = prob.predict_samples(self.imc.Z)
         self.als.fit((users, items), r_ - xzy, shape=shape)
+        self.als.shape_ = tuple(int(v) for v in shape)
         self.reconstruction_err_ = self.score(X, y)
         return self.imc.Z, self.als.user_feats, self.als.item_feats
 
@@ -69,7 +99,8 @@ class DirtyIMC(BaseEstimator):
         check_is_fitted(self, ['imc', 'als'])
         x, y_, users, items = _check_x(X, indices=True)
         uv = self.als._pair_predictions(users, items)
-        xzy = self._xzy(x, y_, self.imc.Z)
+        xzy = self._xzy(x, y_, users, items, self.imc.Z,
+                        self._attribute_form(x, y_, users, items))
         return uv + xzy
 
     def score(self, X, y):

@@ -43,8 +43,7 @@ class ImcProblem(object):
         all-reduce of the p x q result and of the scalar, so all ranks see identical values
         and drive identical optimiser trajectories.  shard = (index, count) selects such a
         range without a group (the caller combines the partial results itself)."""
-        import torch
-        self.device = dev.require_gpu()
+        self._init_device()
         self.group = group
         if group is not None:
             import torch.distributed as dist
@@ -52,7 +51,6 @@ class ImcProblem(object):
             if shard[1] == 1:
                 self.group, shard = None, None
         self.dtype = np.dtype(dtype)
-        lib = _lib.load()
         X_attrs = np.atleast_2d(np.asarray(X_attrs, dtype=np.float64))
         Y_attrs = np.atleast_2d(np.asarray(Y_attrs, dtype=np.float64))
         users = np.asarray(users).ravel().astype(np.int64)
@@ -65,16 +63,13 @@ class ImcProblem(object):
         if users.size and (users.min() < 0 or users.max() >= self.n_users or
                            items.min() < 0 or items.max() >= self.n_items):
             raise IndexError('sample index out of range')
-        self.ld = lib.alsmi_imc_padded_width(self.q)
-        if self.ld == 0:
-            raise ValueError('item attribute count must be between 1 and 256, got %d' % self.q)
+        self.ld = self._padded_width(self.q)
         self.n_samples = int(users.size)
+        self.ratings_host = ratings  # all samples, caller order (score needs every rank's)
         # group the samples by user; `order` maps grouped position -> caller position
         self.order = np.argsort(users, kind='stable')
         indptr = np.zeros(self.n_users + 1, dtype=np.int64)
         np.cumsum(np.bincount(users, minlength=self.n_users), out=indptr[1:])
-        td = dev.torch_dtype(self.dtype)
-        to = lambda a, t: torch.from_numpy(np.ascontiguousarray(a)).to(self.device, t)
         items_g, ratings_g = items[self.order].astype(np.int32), ratings[self.order]
         # this rank's users [ulo, uhi) and their samples [slo, shi) of the grouped order
         self.ulo, self.uhi, self.slo, self.shi = 0, self.n_users, 0, self.n_samples
@@ -91,18 +86,76 @@ class ImcProblem(object):
             Y_attrs, items_g = Y_attrs[uniq], inv.astype(np.int32)
         self.n_local_users = self.uhi - self.ulo
         self.n_local_samples = self.shi - self.slo
+        ypad = np.zeros((Y_attrs.shape[0], self.ld))
+        ypad[:, :self.q] = Y_attrs
+        self._place(indptr, items_g, ratings_g, X_attrs, ypad)
+
+    @classmethod
+    def from_device_csr(cls, indptr, items, ratings, X, Y, dtype=np.float64):
+        """The samples as the CSR structure of the ratings, already on the device (torch
+        tensors: indptr int64 [n_users+1], items int32, ratings, X [n_users x p],
+        Y [n_items x q]); predictions come back in that stored order.  For problems built
+        on the device (synthetic benchmarks); no host copy of the samples is made."""
+        import torch
+        self = cls.__new__(cls)
+        self._init_device()
+        self.group = None
+        self.dtype = np.dtype(dtype)
+        self.n_users, self.p = (int(v) for v in X.shape)
+        self.n_items, self.q = (int(v) for v in Y.shape)
+        self.ld = self._padded_width(self.q)
+        self.n_samples = int(items.numel())
+        self.ratings_host = None
+        self.order = None
+        self.ulo, self.uhi, self.slo, self.shi = 0, self.n_users, 0, self.n_samples
+        self.n_local_users, self.n_local_samples = self.n_users, self.n_samples
+        td = dev.torch_dtype(self.dtype)
+        self.indptr = indptr.to(self.device, torch.int64).contiguous()
+        self.items = items.to(self.device, torch.int32).contiguous()
+        self.ratings = ratings.to(self.device, td).contiguous()
+        self.X = X.to(self.device, td).contiguous()
+        self.Y = torch.zeros((self.n_items, self.ld), dtype=td, device=self.device)
+        self.Y[:, :self.q] = Y.to(self.device, td)
+        self._alloc_workspace()
+        return self
+
+    # ---- device side (the test suite's CPU stand-in overrides these four) -----------------
+    def _init_device(self):
+        import torch
+        self._torch = torch
+        self.device = dev.require_gpu()
+
+    def _padded_width(self, q):
+        ld = _lib.load().alsmi_imc_padded_width(int(q))
+        if ld == 0:
+            raise ValueError('item attribute count must be between 1 and 256, got %d' % q)
+        return ld
+
+    def _place(self, indptr, items_g, ratings_g, X_attrs, ypad):
+        torch = self._torch
+        td = dev.torch_dtype(self.dtype)
+        to = lambda a, t: torch.from_numpy(np.ascontiguousarray(a)).to(self.device, t)
         self.indptr = to(indptr, torch.int64)
         self.items = to(items_g, torch.int32)
         self.ratings = to(ratings_g, td)
         self.X = to(X_attrs, td)
-        ypad = np.zeros((Y_attrs.shape[0], self.ld))
-        ypad[:, :self.q] = Y_attrs
         self.Y = to(ypad, td)
-        nbytes = int(lib.alsmi_imc_workspace_bytes(_lib.dtype_code(self.dtype),
-                                                   max(self.n_local_users, 1), self.p, self.q))
+        self._alloc_workspace()
+
+    def _alloc_workspace(self):
+        torch = self._torch
+        self._td = dev.torch_dtype(self.dtype)
+        nbytes = int(_lib.load().alsmi_imc_workspace_bytes(
+            _lib.dtype_code(self.dtype), max(self.n_local_users, 1), self.p, self.q))
         self.workspace = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self.device)
-        self._torch = torch
-        self._td = td
+
+    def _run(self, mode, Md, r, out, local_pred, sse):
+        """One pass of the kernels over this rank's samples."""
+        _lib.check(_lib.load().alsmi_imc_eval(
+            _lib.dtype_code(self.dtype), int(mode), self.n_local_users, self.p, self.q,
+            dev._ptr(self.indptr), dev._ptr(self.items), dev._ptr(r), dev._ptr(self.X),
+            dev._ptr(self.Y), dev._ptr(Md), dev._ptr(out), dev._ptr(local_pred),
+            dev._ptr(sse), dev._ptr(self.workspace), dev._stream()), 'alsmi_imc_eval')
 
     def _eval(self, mode, M, want_out=True, want_sse=False, want_pred=False, ratings=None):
         torch = self._torch
@@ -121,11 +174,7 @@ class ImcProblem(object):
                     np.zeros(0) if want_pred else None)
         if self.n_local_users > 0 and self.n_local_samples > 0:
             local_pred = pred[self.slo:self.shi] if want_pred else None
-            _lib.check(_lib.load().alsmi_imc_eval(
-                _lib.dtype_code(self.dtype), int(mode), self.n_local_users, self.p, self.q,
-                dev._ptr(self.indptr), dev._ptr(self.items), dev._ptr(r), dev._ptr(self.X),
-                dev._ptr(self.Y), dev._ptr(Md), dev._ptr(out), dev._ptr(local_pred),
-                dev._ptr(sse), dev._ptr(self.workspace), dev._stream()), 'alsmi_imc_eval')
+            self._run(mode, Md, r, out, local_pred, sse)
         if self.group is not None:
             import torch.distributed as dist
             for t in (out, sse, pred):
@@ -136,8 +185,11 @@ class ImcProblem(object):
         pred_h = None
         if want_pred:
             grouped = pred.to(torch.float64).cpu().numpy()
-            pred_h = np.empty_like(grouped)
-            pred_h[self.order] = grouped
+            if self.order is None:
+                pred_h = grouped
+            else:
+                pred_h = np.empty_like(grouped)
+                pred_h[self.order] = grouped
         return out_h, sse_h, pred_h
 
     # the three callbacks, with the reference's regulariser terms added on the host
@@ -257,15 +309,56 @@ def _fit_imc(X, Y, R, Z=None, method='Newton-CG', n_components=None,
     return _fit_problem(prob, Z, method, alpha, verbose)
 
 
+def _fit_low_rank(prob, r, Z, method, alpha, verbose):
+    """Extension with no counterpart in the reference (which validates ``n_components`` and
+    then ignores it, src/imc.py:148-154): minimise over Z = U V^T of rank r,
+
+        f(U, V) = 0.5 * (sum_e (r_e - x_u^T U V^T y_i)^2 + alpha (||U||^2 + ||V||^2)),
+        df/dU = G V + alpha U,   df/dV = G^T U + alpha V,   G = X^T diag(pred - r) Y,
+
+    G coming from the same device evaluation as the full-rank gradient.  Starts from the
+    best rank-r approximation of the reference's initial Z (src/imc.py:157-159) or of the
+    given Z.  Returns ``(U V^T, U, V, success, message)``."""
+    Z0 = prob.init_z() if Z is None else np.asarray(Z, dtype=np.float64)
+    u, s, vt = np.linalg.svd(Z0, False)
+    root = np.sqrt(s[:r])
+    U0, V0 = u[:, :r] * root, vt[:r].T * root
+    p, q = prob.p, prob.q
+
+    def unpack(a):
+        return a[:p * r].reshape(p, r), a[p * r:].reshape(q, r)
+
+    def fun(a):
+        U, V = unpack(a)
+        G, sse, _ = prob._eval(0, U.dot(V.T), want_sse=True)
+        f = 0.5 * (sse + alpha * (np.sum(U * U) + np.sum(V * V)))
+        g = np.concatenate(((G.dot(V) + alpha * U).ravel(), (G.T.dot(U) + alpha * V).ravel()))
+        return f, g
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=RuntimeWarning)
+        res = so.minimize(fun, np.concatenate((U0.ravel(), V0.ravel())), jac=True,
+                          method='L-BFGS-B' if method == 'Newton-CG' else method,
+                          options={'disp': verbose} if verbose else {})
+    U, V = unpack(res['x'])
+    return U.dot(V.T), U, V, res.success, res.message
+
+
 class IMC(BaseEstimator):
-    """Inductive matrix completion estimator (src/imc.py:173-356)."""
+    """Inductive matrix completion estimator (src/imc.py:173-356).
+
+    ``low_rank`` (extension, default off = the reference's behaviour, in which
+    ``n_components`` is validated and recorded but Z stays a full p x q matrix): when true
+    and ``n_components`` is smaller than both attribute counts, Z is constrained to
+    U V^T with ``n_components`` columns (attributes ``U_``, ``V_``); see ``_fit_low_rank``."""
 
     def __init__(self, n_components=None, method='Newton-CG', alpha=0.1,
-                 verbose=0):
+                 verbose=0, low_rank=False):
         self.n_components = n_components
         self.method = method
         self.alpha = alpha
         self.verbose = verbose
+        self.low_rank = low_rank
 
     @staticmethod
     def _problem(X, y):
@@ -277,10 +370,10 @@ class IMC(BaseEstimator):
                               group=default_group())
         return problem_from_samples(x, y_, y)
 
-    def fit_transform(self, X, y, Z=None):
-        """Learn Z for the given data and return it (src/imc.py:220-254)."""
-        x, _ = _check_x(X)
-        n_features = np.atleast_2d(x).shape[1]
+    def _fit_on(self, prob, Z=None):
+        """Fit on an index-form problem (the shared tail of fit_transform; DirtyIMC calls it
+        directly with attribute matrices and sample indices)."""
+        n_features = prob.p
         if self.n_components and self.n_components < n_features:
             self.n_components_ = self.n_components
         else:
@@ -288,14 +381,21 @@ class IMC(BaseEstimator):
         if not isinstance(self.n_components_, INTEGER_TYPES) or self.n_components_ <= 0:
             raise ValueError("Number of components must be a positive integer;"
                              " got (n_components=%r)." % self.n_components_)
-        prob = self._problem(X, y)
-        Z, success, msg = _fit_problem(prob, Z, self.method, self.alpha, self.verbose)
+        if self.low_rank and self.n_components_ < min(prob.p, prob.q):
+            Z, self.U_, self.V_, success, msg = _fit_low_rank(
+                prob, self.n_components_, Z, self.method, self.alpha, self.verbose)
+        else:
+            Z, success, msg = _fit_problem(prob, Z, self.method, self.alpha, self.verbose)
         if not success:
             warnings.warn(msg, ConvergenceWarning, stacklevel=1)
         self.Z = Z
         sse = prob.sse(Z)
         self.reconstruction_err_ = float(np.sqrt(sse / prob.n_samples))
         return Z
+
+    def fit_transform(self, X, y, Z=None):
+        """Learn Z for the given data and return it (src/imc.py:220-254)."""
+        return self._fit_on(self._problem(X, y), Z)
 
     def fit(self, X, y, Z=None):
         """src/imc.py:256-276."""
@@ -336,7 +436,7 @@ class IMC(BaseEstimator):
         (src/imc.py:333-356; note the sign differs from ALS and DirtyIMC)."""
         check_is_fitted(self, 'n_components_')
         prob = self._problem(X, y)
+        # the predictions are all-reduced over the ranks of a group; the truth is the full
+        # host vector every rank was given
         preds = prob.predict_samples(self.Z)
-        truth = np.empty(prob.n_samples)
-        truth[prob.order] = prob.ratings.to(prob._torch.float64).cpu().numpy()
-        return root_mean_squared_error(truth, preds)
+        return root_mean_squared_error(prob.ratings_host, preds)

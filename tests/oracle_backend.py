@@ -83,3 +83,47 @@ class OracleBackend(object):
         pred = (u * v).sum(-1)
         sse = ((vals - pred) ** 2).sum().reshape(1) if vals is not None else None
         return (pred if want_pred else None), sse
+
+
+def make_oracle_imc_problem():
+    """CPU stand-in for alsmi.imc.ImcProblem (same class, device side replaced by the numpy /
+    C oracle), so that the sample sharding and the all-reduces of the IMC evaluations can run
+    under gloo without a GPU."""
+    from alsmi.imc import ImcProblem
+
+    class OracleImcProblem(ImcProblem):
+        def _init_device(self):
+            self._torch = torch
+            self.device = torch.device('cpu')
+
+        def _padded_width(self, q):
+            if not 1 <= q <= 256:
+                raise ValueError('item attribute count must be between 1 and 256, got %d' % q)
+            ld = 16
+            while ld < q:
+                ld *= 2
+            return ld
+
+        def _place(self, indptr, items_g, ratings_g, X_attrs, ypad):
+            self.indptr = torch.from_numpy(np.ascontiguousarray(indptr, dtype=np.int64))
+            self.items = torch.from_numpy(np.ascontiguousarray(items_g, dtype=np.int32))
+            self.ratings = torch.from_numpy(np.ascontiguousarray(ratings_g, dtype=np.float64))
+            self.X = torch.from_numpy(np.ascontiguousarray(X_attrs, dtype=np.float64))
+            self.Y = torch.from_numpy(np.ascontiguousarray(ypad, dtype=np.float64))
+            self._td = torch.float64
+
+        def _run(self, mode, Md, r, out, local_pred, sse):
+            Y = self.Y[:, :self.q].numpy()
+            M = Md.numpy().astype(np.float64)
+            got, s = co.imc_eval(int(mode), self.indptr.numpy(), self.items.numpy(), r.numpy(),
+                                 self.X.numpy(), Y, M, threads=1)
+            if out is not None:
+                out.copy_(torch.from_numpy(got))
+            if sse is not None:
+                sse[0] = s
+            if local_pred is not None:
+                A = self.X.numpy().dot(M)
+                rows = np.repeat(np.arange(self.n_local_users), np.diff(self.indptr.numpy()))
+                local_pred.copy_(torch.from_numpy((A[rows] * Y[self.items.numpy()]).sum(-1)))
+
+    return OracleImcProblem

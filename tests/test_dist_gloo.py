@@ -121,3 +121,82 @@ def test_split_by_nnz():
     # more parts than rows still gives monotone bounds ending at n
     b = split_by_nnz(np.array([0, 5], dtype=np.int64), 3)
     assert b[0] == 0 and b[-1] == 1 and np.all(np.diff(b) >= 0)
+
+
+# ---- IMC on several ranks: samples sharded by user range, all-reduced evaluations -----------
+
+def imc_worker(rank_id, world, port, out_dir):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE),
+                                                  'recommendation-models_amd'), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import warnings
+    import torch.distributed as dist
+    import alsmi.imc as imc_mod
+    from oracle_backend import make_oracle_imc_problem
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank_id, world_size=world)
+    try:
+        Problem = make_oracle_imc_problem()
+        imc_mod.ImcProblem = Problem          # the estimator builds its problems from this name
+        X, Y, users, items, r, Z, S = imc_case()
+        prob = Problem(X, Y, users, items, r, group=dist.group.WORLD)
+        assert 0 < prob.n_local_samples < r.size     # really sharded
+        res = dict(cost=prob.cost(Z, 0.3), grad=prob.grad(Z, 0.3), hessp=prob.hessp(S, 0.3),
+                   z0=prob.init_z(), pred=prob.predict_samples(Z), n_local=prob.n_local_samples)
+        # the estimator end to end on the sharded problem: fit, training error, score
+        import scipy.sparse as sps
+        R = sps.csr_matrix((r, (users, items)), shape=(X.shape[0], Y.shape[0]))
+        est = imc_mod.IMC(alpha=0.3)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            est.fit((X, Y), R)
+        res.update(fit_Z=est.Z, fit_err=est.reconstruction_err_, score=est.score((X, Y), R))
+        np.savez(os.path.join(out_dir, 'imc%d.npz' % rank_id), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def imc_case():
+    rng = np.random.default_rng(17)
+    n, m, p, q, ns = 60, 45, 7, 19, 700
+    flat = rng.choice(n * m, size=ns, replace=False)
+    users, items = flat // m, flat % m
+    users[users == 4] = 5                      # a user without samples
+    keep = np.unique(users * m + items, return_index=True)[1]
+    users, items = users[keep], items[keep]
+    X, Y = rng.standard_normal((n, p)), rng.standard_normal((m, q))
+    return (X, Y, users, items, rng.standard_normal(users.size), rng.standard_normal((p, q)),
+            rng.standard_normal((p, q)))
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_imc_sharded_evaluations_match_single_process(tmp_path, world):
+    import warnings
+    from oracle import imc_oracle as io
+    port = free_port()
+    mp.spawn(imc_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    X, Y, users, items, r, Z, S = imc_case()
+    outs = [np.load(os.path.join(str(tmp_path), 'imc%d.npz' % k)) for k in range(world)]
+    assert sum(int(o['n_local']) for o in outs) == r.size
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fit_Z, _, _ = io.fit_imc(X[users], Y[items], r, alpha=0.3)
+    fit_err = io.imc_score(fit_Z, X[users], Y[items], r)
+    for o in outs:
+        np.testing.assert_allclose(o['cost'], io.cost_indexed(Z, X, Y, users, items, r, 0.3),
+                                   rtol=1e-12)
+        np.testing.assert_allclose(o['grad'], io.grad_indexed(Z, X, Y, users, items, r, 0.3),
+                                   rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(o['hessp'], io.hessp_indexed(S, X, Y, users, items, 0.3),
+                                   rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(o['z0'], io.init_z(X, Y, users, items, r), rtol=1e-9,
+                                   atol=1e-12)
+        np.testing.assert_allclose(o['pred'], io.preds_indexed(Z, X, Y, users, items),
+                                   rtol=1e-11, atol=1e-12)
+        # every rank drives the same optimiser trajectory and scores all samples
+        np.testing.assert_allclose(o['fit_Z'], fit_Z, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(o['fit_err'], fit_err, rtol=1e-6)
+        np.testing.assert_allclose(o['score'], fit_err, rtol=1e-6)
+        assert np.array_equal(o['fit_Z'], outs[0]['fit_Z'])

@@ -221,3 +221,119 @@ def test_rank128_source_table_above_4gib():
     plan.close()
     del table
     torch.cuda.empty_cache()
+
+
+# ---- BASELINE config 3: IMC with dense side features at the full shape ----------------------
+# users x 128 and items x 256 attributes over the 138 493 x 26 744 / 20 M-entry ratings.  The C
+# restatement covers the whole problem on the host cores in seconds, so the p x q results and
+# the squared error are compared directly, in fp64 and in fp32.
+
+@pytest.fixture(scope='module')
+def imc_problem(problem):
+    torch, device = problem['torch'], problem['device']
+    P = problem['prob']
+    p, q = 128, 256
+    g = torch.Generator(device=device)
+    g.manual_seed(3)
+    X = torch.randn((N_USERS, p), generator=g, device=device, dtype=torch.float64) / np.sqrt(p)
+    Y = torch.randn((N_ITEMS, q), generator=g, device=device, dtype=torch.float64) / np.sqrt(q)
+    # fp32-exact inputs, so that both builds see the same numbers
+    X, Y = X.float().double(), Y.float().double()
+    M = (torch.randn((p, q), generator=g, device=device, dtype=torch.float64) * 0.1).float().double()
+    from oracle import c_oracle as co
+    indptr, items, vals = problem['host']['csr']
+    Xh, Yh, Mh = X.cpu().numpy(), Y.cpu().numpy(), M.cpu().numpy()
+    vals64 = vals.astype(np.float64)
+    want = {mode: co.imc_eval(mode, indptr, items, vals64, Xh, Yh, Mh, threads=16)
+            for mode in (0, 1)}
+    # predictions of a sample of users (the longest, the shortest, random ones)
+    rows, _ = sample_rows(indptr, 60, 5)
+    A = Xh[rows].dot(Mh)
+    preds = {}
+    for k, r in enumerate(rows):
+        lo, hi = int(indptr[r]), int(indptr[r + 1])
+        preds[int(r)] = (lo, hi, Yh[items[lo:hi]].dot(A[k]))
+    return dict(X=X, Y=Y, M=Mh, want=want, preds=preds, csr=P['csr'])
+
+
+@pytest.mark.parametrize('dtype,tol_out,tol_sse,tol_pred', [('float64', 1e-10, 1e-11, 1e-11),
+                                                            ('float32', 2e-4, 2e-6, 2e-5)])
+def test_imc_evaluations_at_full_size(imc_problem, dtype, tol_out, tol_sse, tol_pred):
+    from alsmi.imc import ImcProblem
+    I = imc_problem
+    indptr, items, vals = I['csr']
+    prob = ImcProblem.from_device_csr(indptr, items, vals, I['X'], I['Y'], dtype=dtype)
+    out0, sse, pred = prob._eval(0, I['M'], want_sse=True, want_pred=True)
+    out1, _, _ = prob._eval(1, I['M'])
+    want0, want_sse = I['want'][0]
+    want1, _ = I['want'][1]
+    assert np.abs(out0 - want0).max() <= tol_out * np.abs(want0).max()
+    assert np.abs(out1 - want1).max() <= tol_out * np.abs(want1).max()
+    np.testing.assert_allclose(sse, want_sse, rtol=tol_sse)
+    for r, (lo, hi, want_p) in I['preds'].items():
+        scale = max(np.abs(want_p).max(), 1e-30) if hi > lo else 1.0
+        assert np.abs(pred[lo:hi] - want_p).max() <= tol_pred * scale, r
+    # linearity of the Hessian-vector part in its argument
+    out2, _, _ = prob._eval(1, 2.0 * I['M'])
+    assert np.abs(out2 - 2.0 * out1).max() <= (1e-12 if dtype == 'float64' else 1e-5) * np.abs(out1).max()
+
+
+def test_dimc_config5_slice_properties():
+    """One GPU's share of BASELINE config 5 (100 M samples over 8 GPUs): 250 000 users x
+    200 000 items, 12.5 M samples, user x 128 and item x 256 attribute matrices in the
+    attribute form (the per-sample form would be 38 GB), planted X Z Y^T plus a rank-8
+    residual plus noise.  Too large for the oracle: size-independent properties."""
+    import torch
+    import warnings
+    from alsmi import DirtyIMC, IMC
+    from alsmi import device as dev
+    from alsmi import synth
+    device = dev.require_gpu()
+    n, m, ns, p, q = 250000, 200000, 12500000, 128, 256
+    users_t, items_t, _ = synth.user_block(20245, 0, n, m, ns, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(9)
+    X = torch.randn((n, p), generator=g, device=device, dtype=torch.float64) / np.sqrt(p)
+    Y = torch.randn((m, q), generator=g, device=device, dtype=torch.float64) / np.sqrt(q)
+    Zs = torch.randn((p, 16), generator=g, device=device, dtype=torch.float64).mm(
+        torch.randn((16, q), generator=g, device=device, dtype=torch.float64))
+    A = X.mm(Zs)
+    P8 = torch.randn((n, 8), generator=g, device=device, dtype=torch.float64) * 0.5
+    Q8 = torch.randn((m, 8), generator=g, device=device, dtype=torch.float64) * 0.5
+    side = torch.empty(ns, dtype=torch.float64, device=device)
+    resid = torch.empty(ns, dtype=torch.float64, device=device)
+    for s in range(0, ns, 1 << 20):
+        e = min(ns, s + (1 << 20))
+        side[s:e] = (A[users_t[s:e]] * Y[items_t[s:e]]).sum(-1)
+        resid[s:e] = (P8[users_t[s:e]] * Q8[items_t[s:e]]).sum(-1)
+    noise = torch.randn(ns, generator=g, device=device, dtype=torch.float64) * 0.1
+    vals = (side + resid + noise).cpu().numpy()
+    side_var, resid_var = float(side.var()), float(resid.var())
+    users, items = users_t.cpu().numpy(), items_t.cpu().numpy()
+    Xh, Yh = X.cpu().numpy(), Y.cpu().numpy()
+    del A, side, resid, noise, X, Y
+    args = (Xh, Yh, users, items)
+    # (a tiny imc_alpha: the reference's cost counts the regulariser once per sample,
+    # src/imc.py:47, while its gradient counts it once, so at 12.5 M samples any larger value
+    # makes every step look uphill to the line search)
+    d = DirtyIMC(rank=8, tol=1e-3, random_state=1, imc_alpha=1e-9, als_alpha=0.05)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Z, u, i = d.fit_transform(args, vals, shape=(n, m))
+    assert d._attribute_form(*args)
+    assert Z.shape == (p, q) and u.shape == (8, n) and i.shape == (8, m)
+    assert np.isfinite(Z).all() and np.isfinite(u).all() and np.isfinite(i).all()
+    total_rmse = float(np.sqrt(np.mean(vals ** 2)))
+    imc_rmse = d.imc.reconstruction_err_
+    dimc_rmse = -d.reconstruction_err_
+    # IMC explains the side-feature part, ALS on the residual most of the rest
+    assert imc_rmse < 1.15 * np.sqrt(resid_var + 0.01) and imc_rmse < 0.6 * total_rmse
+    assert dimc_rmse < 0.75 * imc_rmse
+    # score and predict agree with the stored error, on a subset given in another order
+    sel = np.random.default_rng(0).choice(ns, 200000, replace=False)
+    sub = (Xh, Yh, users[sel], items[sel])
+    pred = d.predict(sub)
+    np.testing.assert_allclose(-np.sqrt(np.mean((vals[sel] - pred) ** 2)),
+                               d.score(sub, vals[sel]), rtol=1e-12)
+    full = d.score(args, vals)
+    np.testing.assert_allclose(full, d.reconstruction_err_, rtol=1e-9)

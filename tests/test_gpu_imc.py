@@ -220,3 +220,114 @@ def test_sharded_evaluations_add_up(gpu, parts):
     np.testing.assert_allclose(pred, pred0, rtol=1e-12, atol=1e-13)
     u, sv, v = np.linalg.svd(zinit / ns, False)
     np.testing.assert_allclose(u.dot(np.diag(sv)).dot(v), z0, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('p,q', [(3, 1), (17, 16), (5, 33), (130, 100), (40, 256)])
+def test_evaluations_match_oracle_shapes_fp32(gpu, p, q):
+    """The same shapes in the fp32 build of the kernels (the throughput mode): fp32 products
+    and row sums, fp64 squared-error accumulation."""
+    from alsmi.imc import ImcProblem
+    from oracle import imc_oracle as io
+    rng = np.random.default_rng(p * 1000 + q)
+    n, m, nnz = 70, 50, 900
+    flat = rng.choice(n * m, size=nnz, replace=False)
+    users, items = flat // m, flat % m
+    keep = ~np.isin(users, (0, 13, 69))
+    users, items = users[keep], items[keep]
+    users = np.concatenate([users, np.full(m, 13)])
+    items = np.concatenate([items, np.arange(m)])
+    vals = rng.standard_normal(users.size)
+    # inputs that are exact in fp32, so that only the arithmetic differs
+    X = (rng.standard_normal((n, p)) / np.sqrt(p)).astype(np.float32).astype(np.float64)
+    Y = (rng.standard_normal((m, q)) / np.sqrt(q)).astype(np.float32).astype(np.float64)
+    vals = vals.astype(np.float32).astype(np.float64)
+    Z = rng.standard_normal((p, q)).astype(np.float32).astype(np.float64)
+    S = rng.standard_normal((p, q)).astype(np.float32).astype(np.float64)
+    prob = ImcProblem(X, Y, users, items, vals, dtype=np.float32)
+    want_g = io.grad_indexed(Z, X, Y, users, items, vals, 0.3)
+    want_h = io.hessp_indexed(S, X, Y, users, items, 0.3)
+    np.testing.assert_allclose(prob.cost(Z, 0.3), io.cost_indexed(Z, X, Y, users, items, vals, 0.3),
+                               rtol=1e-5)
+    # tolerance: 1e-4 of the largest entry (sums of ~900 fp32 products with cancellation)
+    assert np.abs(prob.grad(Z, 0.3) - want_g).max() <= 1e-4 * np.abs(want_g).max()
+    assert np.abs(prob.hessp(S, 0.3) - want_h).max() <= 1e-4 * np.abs(want_h).max()
+    want_p = io.preds_indexed(Z, X, Y, users, items)
+    assert np.abs(prob.predict_samples(Z) - want_p).max() <= 1e-5 * max(np.abs(want_p).max(), 1)
+
+
+def test_dimc_attribute_form_matches_sample_form(gpu, golden):
+    """DirtyIMC given one feature row per user / item plus sample indices (nothing expanded
+    to per-sample rows) against the reference's per-sample form and the oracle
+    (src/dimc.py:150-160)."""
+    from alsmi import DirtyIMC
+    from oracle import imc_oracle as io
+    g = golden('dimc')
+    users, items = g['rnd_users'], g['rnd_items']
+    n, m = (int(v) for v in g['rnd_shape'])
+    X, Y, vals = g['rnd_X'], g['rnd_Y'], g['rnd_vals']
+    assert X.shape[0] == n and Y.shape[0] == m and users.size not in (n, m)
+    outs = []
+    for form, args in (('attribute', (X, Y, users, items)),
+                       ('sample', (X[users], Y[items], users, items))):
+        d = DirtyIMC(rank=3, tol=1e-3, random_state=5, imc_alpha=0.1, als_alpha=0.1)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Z, u, i = d.fit_transform(args, vals, shape=(n, m))
+        assert d._attribute_form(*args) == (form == 'attribute')
+        np.testing.assert_allclose(Z, g['rnd_Z'], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(d.reconstruction_err_, g['rnd_err'], rtol=1e-6)
+        np.testing.assert_allclose(d.predict(args), g['rnd_predict'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(d.score(args, vals), g['rnd_err'], rtol=1e-6)
+        outs.append((Z, u, i))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-7, atol=1e-9)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Zo, uo, io_, err, pred = io.dimc_fit(X[users], Y[items], users, items, vals, (n, m), 3,
+                                             0.1, 0.1, 1e-3, 5)
+    np.testing.assert_allclose(outs[0][0], Zo, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(outs[0][1], uo, rtol=1e-5, atol=1e-7)
+    # sparse y with the attribute form, and a row count that fits neither form
+    import scipy.sparse as sps
+    R = sps.csr_matrix((vals, (users, items)), shape=(n, m))
+    d = DirtyIMC(rank=3, tol=1e-3, random_state=5, imc_alpha=0.1, als_alpha=0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        d.fit((X, Y, users, items), R)
+    np.testing.assert_allclose(d.reconstruction_err_, g['rnd_err'], rtol=1e-6)
+    with pytest.raises(ValueError):
+        DirtyIMC(rank=3).fit((X[:-1], Y, users, items), vals, shape=(n, m))
+
+
+def test_low_rank_imc_matches_restatement(gpu):
+    """IMC(low_rank=True): Z = U V^T with n_components columns.  No reference counterpart
+    (parity unpinned): checked against the numpy restatement of the same procedure."""
+    from alsmi import IMC
+    from oracle import imc_oracle as io
+    import scipy.sparse as sps
+    rng = np.random.default_rng(8)
+    n, m, p, q, r, ns = 80, 60, 12, 20, 3, 1500
+    X, Y = rng.standard_normal((n, p)) / np.sqrt(p), rng.standard_normal((m, q)) / np.sqrt(q)
+    flat = rng.choice(n * m, size=ns, replace=False)
+    users, items = flat // m, flat % m
+    Zs = rng.standard_normal((p, r)).dot(rng.standard_normal((r, q)))
+    vals = io.preds_indexed(Zs, X, Y, users, items) + 0.01 * rng.standard_normal(ns)
+    R = sps.csr_matrix((vals, (users, items)), shape=(n, m))
+    est = IMC(n_components=r, alpha=0.01, low_rank=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Z = est.fit_transform((X, Y), R)
+    assert est.n_components_ == r and est.U_.shape == (p, r) and est.V_.shape == (q, r)
+    assert np.linalg.matrix_rank(Z, tol=1e-8) == r
+    rows, cols = R.nonzero()
+    Zo, Uo, Vo = io.fit_low_rank(X, Y, rows, cols, np.asarray(R[rows, cols]).ravel(), r, 0.01)
+    np.testing.assert_allclose(Z, Zo, rtol=1e-4, atol=1e-5)
+    # the planted rank-3 model is recovered, and a full-rank fit is no better on the samples
+    assert est.reconstruction_err_ < 0.05
+    np.testing.assert_allclose(est.score((X, Y), R), est.reconstruction_err_, rtol=1e-9)
+    # default (reference behaviour): n_components is recorded, Z stays full rank
+    ref = IMC(n_components=r, alpha=0.01)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Zf = ref.fit_transform((X, Y), R)
+    assert ref.n_components_ == r and np.linalg.matrix_rank(Zf, tol=1e-8) > r

@@ -175,3 +175,30 @@ def test_dimc_matches_reference(golden):
     np.testing.assert_allclose(Z, g['rnd_Z'], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(err, g['rnd_err'], rtol=1e-6)
     np.testing.assert_allclose(pred, g['rnd_predict'], rtol=1e-5, atol=1e-6)
+
+
+def test_low_rank_imc_gradient_by_finite_differences():
+    """The rank-constrained objective has no reference counterpart (parity unpinned): its
+    restated gradient is checked against central differences of its restated cost."""
+    from oracle import imc_oracle as io
+    rng = np.random.default_rng(3)
+    n, m, p, q, r, ns = 20, 15, 6, 9, 3, 120
+    X, Y = rng.standard_normal((n, p)), rng.standard_normal((m, q))
+    users, items = rng.integers(0, n, ns), rng.integers(0, m, ns)
+    vals = rng.standard_normal(ns)
+    U, V = rng.standard_normal((p, r)), rng.standard_normal((q, r))
+    f, gu, gv = io.low_rank_cost_grad(U, V, X, Y, users, items, vals, 0.2)
+    eps = 1e-6
+    for (mat, grad) in ((U, gu), (V, gv)):
+        for idx in ((0, 0), (2, 1), (mat.shape[0] - 1, r - 1)):
+            keep = mat[idx]
+            mat[idx] = keep + eps
+            fp = io.low_rank_cost_grad(U, V, X, Y, users, items, vals, 0.2)[0]
+            mat[idx] = keep - eps
+            fm = io.low_rank_cost_grad(U, V, X, Y, users, items, vals, 0.2)[0]
+            mat[idx] = keep
+            np.testing.assert_allclose((fp - fm) / (2 * eps), grad[idx], rtol=1e-6, atol=1e-7)
+    Z, U2, V2 = io.fit_low_rank(X, Y, users, items, vals, r, 0.2)
+    assert np.linalg.matrix_rank(Z) == r
+    f_fit = io.low_rank_cost_grad(U2, V2, X, Y, users, items, vals, 0.2)
+    assert f_fit[0] < f and np.abs(f_fit[1]).max() < 1e-3 * max(1.0, np.abs(gu).max())
