@@ -10,12 +10,16 @@ The squared error of a sweep is produced by the user half of the NEXT step, whic
 the same ratings and item factors anyway (the schedule ALS.fit uses); the error of the last
 timed sweep is a standalone pass inside the timed region, so K timed steps contain K user
 halves, K item halves and K+1 error sums.
-With N ranks the problem is N user blocks of the single-GPU size (weak scaling): every
-rank updates its own users and its slice of the items, each half-sweep ends with an
-all-gather of the updated factor rows.  Inputs are resident in HBM before the timed
-region.  Rank 0 prints one JSON line.
+With N ranks the default problem is N user blocks of the single-GPU size (weak scaling);
+`--config c4` is the fixed 10 M x 1 M, 1 B-entry rank-128 matrix cut over the ranks (strong
+scaling).  Every rank updates its own users and its slice of the items, each half-sweep ends
+with an all-gather of the updated factor rows, overlapped slab by slab with the computation.
+Inputs are resident in HBM before the timed region.  Rank 0 prints one JSON line.
 """
 import argparse
+import glob
+import hashlib
+import importlib
 import json
 import os
 import sys
@@ -30,17 +34,22 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 CONFIGS = {
-    # name: users per GPU, items, stored entries per GPU, rank
-    'c2': dict(n=138493, m=26744, nnz=20000000, rank=64,
+    # n, nnz: users and stored entries per BLOCK; blocks: None = one block per rank (weak
+    # scaling), a number = that many blocks in total, shared out over the ranks (strong)
+    'c2': dict(n=138493, m=26744, nnz=20000000, rank=64, blocks=None,
                workload='ALS rank 64, synthetic ML-20M shape 138493x26744, 20M nnz per GPU'),
-    'r128': dict(n=138493, m=26744, nnz=20000000, rank=128,
-                 workload='ALS rank 128, synthetic ML-20M shape 138493x26744, 20M nnz per GPU '
-                          '(single-GPU slice of the rank-128 configuration)'),
-    'c4slice': dict(n=1250000, m=1000000, nnz=125000000, rank=128,
-                    workload='ALS rank 128, one GPU\'s share of the 10M x 1M, 1B-entry configuration '
-                             'at 8 GPUs: 1.25M users x 1M items, 125M nnz'),
-    'small': dict(n=20000, m=5000, nnz=1000000, rank=64,
+    'r128': dict(n=138493, m=26744, nnz=20000000, rank=128, blocks=None,
+                 workload='ALS rank 128, synthetic ML-20M shape 138493x26744, 20M nnz per GPU'),
+    'c4slice': dict(n=1250000, m=1000000, nnz=125000000, rank=128, blocks=None,
+                    workload='ALS rank 128, one GPU\'s share of the 10M x 1M, 1B-entry '
+                             'configuration at 8 GPUs: 1.25M users x 1M items, 125M nnz per GPU'),
+    'c4': dict(n=1250000, m=1000000, nnz=125000000, rank=128, blocks=8,
+               workload='ALS rank 128, 10M users x 1M items, 1B nnz in total (8 user blocks of '
+                        '1.25M users / 125M nnz shared out over the ranks)'),
+    'small': dict(n=20000, m=5000, nnz=1000000, rank=64, blocks=None,
                   workload='ALS rank 64, synthetic 20000x5000, 1M nnz per GPU (smoke size)'),
+    'tiny': dict(n=300, m=200, nnz=6000, rank=8, blocks=None,
+                 workload='ALS rank 8, synthetic 300x200, 6000 nnz per rank (rehearsal size)'),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec
 
@@ -55,6 +64,37 @@ def sddmm_bytes(nnz, rows, kp, s):
     """Training-error pass with row reuse: per entry one item factor row, two int32
     indices and the rating; per user row its factor vector once."""
     return nnz * (kp * s + 8 + s) + rows * kp * s
+
+
+def kernel_source_sha():
+    """Hash of the kernel sources: counters measured on another build are not reported."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'recommendation-models_amd', 'csrc', '*.h*'))):
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def measured_counters(config, dtype):
+    """HBM traffic and MFMA utilisation of this configuration's half-sweep kernels from the
+    newest committed counter summary (profiles/rNN_summary.json, written by
+    tools/profile_collect.py from rocprofv3 --pmc passes of this very command) — only when it
+    was measured on the kernel sources that are running now."""
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json')), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        entry = doc.get('configs', {}).get('%s/%s' % (config, dtype))
+        if entry is None:
+            continue
+        if doc.get('kernel_source_sha') != kernel_source_sha():
+            return {'stale': 'counters in %s were measured on other kernel sources (%s)'
+                             % (os.path.basename(path), doc.get('commit'))}
+        entry = dict(entry)
+        entry['measured_at_commit'] = doc.get('commit')
+        entry['file'] = 'profiles/' + os.path.basename(path)
+        return entry
+    return None
 
 
 def cpu_baseline(engine, frac, threads):
@@ -90,6 +130,104 @@ def cpu_baseline(engine, frac, threads):
                           out['item_entries']))
 
 
+class Stamp(object):
+    """A point in time on the device's current stream (a wall-clock stamp without a GPU)."""
+
+    def __init__(self, cuda):
+        self.cuda = cuda
+        self.ev = torch.cuda.Event(enable_timing=True) if cuda else None
+        self.t = None
+
+    def record(self):
+        if self.cuda:
+            self.ev.record()
+        else:
+            self.t = time.perf_counter()
+
+    def ms_until(self, other):
+        return self.ev.elapsed_time(other.ev) if self.cuda else (other.t - self.t) * 1e3
+
+
+def init_factors(engine, rank, device):
+    """Initial factors as in src/als.py:143-152: uniform item factors with row 0 = mean
+    rating of the item, zero user factors."""
+    m = engine.m
+    csc = engine.csc
+    indptr = csc.indptr_host
+    cnt = torch.from_numpy(np.diff(indptr)).to(device=device, dtype=torch.float64)
+    # per-item sums as differences of a running sum over the item-ordered ratings (an
+    # index_add_ on the few popular items serialises on atomics: 15 s at 125 M entries)
+    run = torch.zeros(csc.nnz + 1, dtype=torch.float64, device=device)
+    torch.cumsum(csc.vals.to(torch.float64), 0, out=run[1:])
+    ptr = torch.from_numpy(indptr).to(device)
+    sums = run[ptr[1:]] - run[ptr[:-1]]
+    del run
+    avg = torch.where(cnt > 0, sums / cnt.clamp_min(1), torch.zeros_like(sums))
+    init = torch.from_numpy(np.random.RandomState(42).rand(rank, m).T.copy()).to(device)
+    engine.V.zero_()
+    engine.V[:, :rank] = init.to(engine.V.dtype)
+    engine.V[engine.ilo:engine.ihi, 0] = avg.to(engine.V.dtype)
+    engine._all_gather_rows(engine.V, engine.item_bounds)
+    engine.U.zero_()
+
+
+def timed_sweeps(engine, steps, warmup, fused, barrier, cuda):
+    """`warmup` untimed and `steps` timed sweeps; returns (elapsed seconds between the two
+    barriers, per-side mean seconds, seconds of the closing error pass or None, rmse list)."""
+    sse_log = []
+
+    def step(stamps=None):
+        if stamps:
+            stamps[0].record()
+        if fused:
+            sse_log.append(engine.half_sweep_users_err())  # error of the state before
+        else:
+            engine.half_sweep_users()
+        if stamps:
+            stamps[1].record()
+        engine.half_sweep_items()
+        if stamps:
+            stamps[2].record()
+        if not fused:
+            sse_log.append(engine.train_sse_async())
+
+    for _ in range(warmup):
+        step()
+    engine.train_sse_async()  # untimed: first-use set-up of the standalone error pass
+    st = [[Stamp(cuda) for _ in range(3)] for _ in range(steps)]
+    tail = [Stamp(cuda), Stamp(cuda)]
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        step(st[s])
+    tail[0].record()
+    if fused:
+        sse_log.append(engine.train_sse_async())  # error of the last timed sweep
+    tail[1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t_user = float(np.mean([st[s][0].ms_until(st[s][1]) for s in range(steps)])) * 1e-3
+    t_item = float(np.mean([st[s][1].ms_until(st[s][2]) for s in range(steps)])) * 1e-3
+    t_sse = tail[0].ms_until(tail[1]) * 1e-3 if fused else None
+    rmse = [float(np.sqrt(float(x.cpu()[0]) / engine.nnz)) for x in sse_log]
+    return elapsed, t_user, t_item, t_sse, rmse
+
+
+def side_report(ms, algo_bytes, counters, side):
+    """Per-side roofline entry: algorithmic rate, and from the committed counters (when they
+    belong to this build) the HBM-side rate and what the kernel is therefore bound by."""
+    out = {'ms': ms * 1e3, 'GBps': algo_bytes / ms / 1e9, 'algorithmic_bytes': algo_bytes}
+    c = (counters or {}).get(side)
+    if c:
+        out['hbm_measured_bytes'] = c['hbm_bytes']
+        out['hbm_measured_GBps'] = c['hbm_bytes'] / ms / 1e9
+        out['mfma_util'] = c.get('mfma_util')
+        # traffic well below the algorithmic bytes: the gathered table is served from
+        # L2 / Infinity Cache and the launch is bound by instruction issue, not by HBM
+        out['bound'] = 'hbm' if c['hbm_bytes'] >= 0.5 * algo_bytes else 'issue/l2'
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -103,6 +241,8 @@ def main():
                          'instead of inside the next user half-sweep (A/B aid)')
     ap.add_argument('--cpu-frac', type=float, default=0.25,
                     help='fraction of rows the CPU baseline is timed on (0 disables it)')
+    ap.add_argument('--no-f64', action='store_true',
+                    help='skip the float64 companion measurement of the default run')
     args = ap.parse_args()
 
     if os.environ.get('ALSMI_BENCH_WATCHDOG'):  # debugging aid: traceback + exit after N s
@@ -116,101 +256,85 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
         args.gpus = world
     # ALSMI_DIST_BACKEND=gloo lets several ranks share one GPU (a rehearsal of the multi-rank
-    # path on a one-GPU box; RCCL wants one device per rank)
-    backend = os.environ.get('ALSMI_DIST_BACKEND', 'nccl')
-    if backend != 'nccl':
-        local = local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
+    # path on a one-GPU box; RCCL wants one device per rank).  ALSMI_BENCH_BACKEND=module:Class
+    # replaces the engine's device backend by another implementation on host tensors (the test
+    # suite rehearses this script's multi-rank logic that way on machines without a GPU).
+    dist_backend = os.environ.get('ALSMI_DIST_BACKEND', 'nccl')
+    plug = os.environ.get('ALSMI_BENCH_BACKEND')
+    cuda = plug is None
+    engine_backend = None
+    if plug:
+        mod, cls = plug.split(':')
+        engine_backend = getattr(importlib.import_module(mod), cls)()
+        device = torch.device('cpu')
+        dist_backend = 'gloo'
+    else:
+        if dist_backend != 'nccl':
+            local = local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
+        if dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(dist_backend)
         group = dist.group.WORLD
 
     from alsmi import synth
     from alsmi.engine import AlsEngine
     cfg = CONFIGS[args.config]
+    if cfg['blocks'] and cfg['blocks'] % world:
+        raise SystemExit('--config %s needs a rank count that divides %d'
+                         % (args.config, cfg['blocks']))
     t_gen = time.perf_counter()
-    prob = synth.sharded_problem(20242, cfg['n'], cfg['m'], cfg['nnz'], world, rank_id, device)
-    torch.cuda.synchronize()
+    prob = synth.sharded_problem(20242, cfg['n'], cfg['m'], cfg['nnz'], world, rank_id, device,
+                                 n_blocks=cfg['blocks'])
+    if cuda:
+        torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    engine = AlsEngine(prob['csr'], prob['csc'], prob['shape'], cfg['rank'], 0.1,
-                       dtype=args.dtype, user_bounds=prob['user_bounds'],
-                       item_bounds=prob['item_bounds'], group=group, chunk=args.chunk,
-                       total_nnz=prob['total_nnz'])
-    del prob
-    # initial factors as in src/als.py:143-152 (row 0 of the item factors = mean rating)
-    m = engine.m
-    csc = engine.csc
-    cnt = torch.diff(csc.indptr).to(torch.float64)
-    # per-item sums as differences of a running sum over the item-ordered ratings (an
-    # index_add_ on the few popular items serialises on atomics: 15 s at 125 M entries)
-    run = torch.zeros(csc.nnz + 1, dtype=torch.float64, device=device)
-    torch.cumsum(csc.vals.to(torch.float64), 0, out=run[1:])
-    sums = run[csc.indptr[1:]] - run[csc.indptr[:-1]]
-    del run
-    avg = torch.where(cnt > 0, sums / cnt.clamp_min(1), torch.zeros_like(sums))
-    init = torch.from_numpy(np.random.RandomState(42).rand(cfg['rank'], m).T.copy()).to(device)
-    engine.V.zero_()
-    engine.V[:, :cfg['rank']] = init.to(engine.V.dtype)
-    engine.V[engine.ilo:engine.ihi, 0] = avg.to(engine.V.dtype)
-    engine._all_gather_rows(engine.V, engine.item_bounds)
-    engine.U.zero_()
+
+    def make_engine(dtype):
+        eng = AlsEngine(prob['csr'], prob['csc'], prob['shape'], cfg['rank'], 0.1, dtype=dtype,
+                        user_bounds=prob['user_bounds'], item_bounds=prob['item_bounds'],
+                        group=group, chunk=args.chunk, total_nnz=prob['total_nnz'],
+                        backend=engine_backend)
+        init_factors(eng, cfg['rank'], device)
+        return eng
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        if cuda:
+            torch.cuda.synchronize()
 
     fused = not args.separate_error
-    sse_log = []
-
-    def step(events=None):
-        if events:
-            events[0].record()
-        if fused:
-            sse_log.append(engine.half_sweep_users_err())  # error of the state before
-        else:
-            engine.half_sweep_users()
-        if events:
-            events[1].record()
-        engine.half_sweep_items()
-        if events:
-            events[2].record()
-        if not fused:
-            sse_log.append(engine.train_sse_async())
-
-    for _ in range(args.warmup):
-        step()
-    engine.train_sse_async()  # untimed: first-use set-up of the standalone error pass
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    ev_tail = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(ev[s])
-    ev_tail[0].record()
-    if fused:
-        sse_log.append(engine.train_sse_async())  # error of the last timed sweep
-    ev_tail[1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    engine = make_engine(args.dtype)
+    elapsed, t_user, t_item, t_sse, rmse = timed_sweeps(engine, args.steps, args.warmup, fused,
+                                                        barrier, cuda)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.cpu()[0])
 
-    rmse = [float(np.sqrt(float(x.cpu()[0]) / engine.nnz)) for x in sse_log]
-    t_user = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)])) * 1e-3
-    t_item = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(args.steps)])) * 1e-3
-    t_sse = ev_tail[0].elapsed_time(ev_tail[1]) * 1e-3 if fused else None
+    # float64 companion (the reference's arithmetic, the 1e-10 parity mode) for the default
+    # single-GPU run: same problem, same schedule, a few sweeps after the timed region
+    f64 = None
+    if world == 1 and args.dtype == 'float32' and args.config == 'c2' and not args.no_f64 and cuda:
+        eng64 = make_engine('float64')
+        e64, u64, i64, _, r64 = timed_sweeps(eng64, 3, 1, fused, barrier, cuda)
+        b64 = half_sweep_bytes(eng64.csr.nnz, eng64.csr.n_rows, eng64.kp, 8) + \
+            half_sweep_bytes(eng64.csc.nnz, eng64.csc.n_rows, eng64.kp, 8)
+        f64 = {'dtype': 'f64 (v_mfma_f64_16x16x4 Gram, in-register Gauss-Jordan solve)',
+               'ms_per_step': e64 / 3 * 1e3, 'sweeps_per_sec': 3 / e64,
+               'user_ms': u64 * 1e3, 'item_ms': i64 * 1e3,
+               'roofline_frac': b64 / (u64 + i64) / 1e9 / HBM_PEAK_GBS,
+               'train_rmse_last': r64[-1] if r64 else None}
+        del eng64
 
     if rank_id == 0:
         s = 4 if args.dtype == 'float32' else 8
@@ -221,35 +345,45 @@ def main():
         b_item = half_sweep_bytes(engine.csc.nnz, engine.csc.n_rows, kp, s)
         b_sse = sddmm_bytes(engine.csr.nnz, engine.csr.n_rows, kp, s)
         achieved = (b_user + b_item) / (t_user + t_item) / 1e9
+        counters = measured_counters(args.config, args.dtype) if world == 1 else None
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath) and world == 1 and args.config == 'c2':
-            try:
-                traffic = json.load(open(tpath)).get('half_sweep_hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        if counters and 'user_side' in counters:
+            traffic = (counters['user_side']['hbm_bytes'] + counters['item_side']['hbm_bytes']) / 2
         sweeps_per_sec = args.steps / elapsed
+        strong = bool(cfg['blocks'])
         line = {
-            'metric': 'ALS nnz/sec (stored entries x sweeps/sec), ML-20M shape rank %d' % cfg['rank'],
+            'metric': ('ALS nnz/sec (stored entries x sweeps/sec), ML-20M shape rank %d'
+                       if args.config in ('c2', 'r128') else
+                       'ALS nnz/sec (stored entries x sweeps/sec), rank %d') % cfg['rank'],
             'value': engine.nnz * sweeps_per_sec,
             'unit': 'nnz/s',
             'sweeps_per_sec': sweeps_per_sec,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.dtype == 'float32' else 'f64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+            'vs_baseline': None,
+            'dtype': ('f32 (products on the fp16 matrix cores from a scaled two-way fp16 split '
+                      'of the fp32 factors, fp32 accumulate and solve; fp32-level accuracy)'
+                      if args.dtype == 'float32' else 'f64'),
+            'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'users': engine.n, 'items': engine.m,
                        'nnz': engine.nnz, 'rank': cfg['rank'], 'alpha': 0.1,
                        'parallelism': 'row-sharded x%d' % world},
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'kernel': 'half-sweep launch = gram_chunks_kernel + solve_rows_kernel, '
-                          'mean of user side and item side',
+                'note': 'achieved = algorithmic bytes (uncached model: every stored entry '
+                        'fetches one factor row) / HIP-event time; where the measured HBM '
+                        'traffic is far below them the gathered table is cache resident and '
+                        'the side is bound by instruction issue (see the per-side entries)',
+                'kernel': 'half-sweep launch = max_abs + gram_chunks + sum_slabs + solve_rows '
+                          '(+ solve_rows_dual at padded rank 128), mean of user side and item side',
                 'bytes_per_launch': (b_user + b_item) / 2.0,
                 'ms_per_launch': (t_user + t_item) / 2.0 * 1e3,
-                'user_side': {'ms': t_user * 1e3, 'GBps': b_user / t_user / 1e9},
-                'item_side': {'ms': t_item * 1e3, 'GBps': b_item / t_item / 1e9},
+                'user_side': side_report(t_user, b_user, counters, 'user_side'),
+                'item_side': side_report(t_item, b_item, counters, 'item_side'),
+                'counters': ({k: v for k, v in counters.items()
+                              if k not in ('user_side', 'item_side')} if counters else None),
             },
             'error_pass': ({'schedule': 'fused into the next user half-sweep; one standalone '
                                         'pass after the last timed sweep',
@@ -259,7 +393,9 @@ def main():
             'train_rmse': {'first': rmse[0] if rmse else None, 'last': rmse[-1] if rmse else None},
             'setup_s': {'generate': t_gen},
         }
-        if world == 1 and args.cpu_frac > 0:
+        if f64:
+            line['f64'] = f64
+        if world == 1 and args.cpu_frac > 0 and cuda:
             threads = int(os.environ.get('OMP_NUM_THREADS', '0')) or min(16, os.cpu_count() or 1)
             try:
                 line['cpu_baseline'] = cpu_baseline(engine, args.cpu_frac, threads)

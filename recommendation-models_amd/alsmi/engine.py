@@ -74,7 +74,7 @@ class AlsEngine(object):
 
     def __init__(self, csr, csc, shape, rank, alpha, dtype=np.float64, user_bounds=None,
                  item_bounds=None, group=None, backend=None, chunk=0, total_nnz=None,
-                 user_slabs=None):
+                 user_slabs=None, item_slabs=None):
         self.backend = backend if backend is not None else LocalBackend()
         self.n, self.m = int(shape[0]), int(shape[1])
         self.rank, self.alpha = int(rank), float(alpha)
@@ -97,16 +97,23 @@ class AlsEngine(object):
         b = self.backend
         self.csr = b.make_side(csr[0], csr[1], csr[2], self.uhi - self.ulo, self.m, self.dtype)
         self.csc = b.make_side(csc[0], csc[1], csc[2], self.ihi - self.ilo, self.n, self.dtype)
-        # The user table is the large one (its all-gather is what a multi-rank sweep waits
-        # for), so with several ranks the user half runs as a few row slabs, balanced by
-        # entries, and the gather of one slab travels while the next is computed.
+        # With several ranks each half runs as a few row slabs, balanced by entries, and the
+        # all-gather of one slab travels while the next is computed (the user table is the
+        # large one: N x 35 MB at 138 493 users per rank and rank 64, 5 GB at 10 M users and
+        # rank 128).
         if user_slabs is None:
             user_slabs = int(os.environ.get('ALSMI_USER_SLABS', '0')) or \
                 (1 if self.world == 1 else 4)
+        if item_slabs is None:
+            item_slabs = int(os.environ.get('ALSMI_ITEM_SLABS', '0')) or \
+                (1 if self.world == 1 else 2)
         self.u_sub = split_by_nnz(self.csr.indptr_host, max(1, int(user_slabs)))
+        self.i_sub = split_by_nnz(self.csc.indptr_host, max(1, int(item_slabs)))
         self.plans_u = [b.make_plan(self.csr, self.rank, chunk, int(lo), int(hi))
                         for lo, hi in zip(self.u_sub[:-1], self.u_sub[1:])]
-        self.plan_i = b.make_plan(self.csc, self.rank, chunk)
+        self.plans_i = [b.make_plan(self.csc, self.rank, chunk, int(lo), int(hi))
+                        for lo, hi in zip(self.i_sub[:-1], self.i_sub[1:])]
+        self.plan_i = self.plans_i[0]
         self.kp = b.padded_rank(self.rank)
         self.U = b.zeros(self.n, self.kp, self.dtype)
         self.V = b.zeros(self.m, self.kp, self.dtype)
@@ -122,19 +129,39 @@ class AlsEngine(object):
                 dist.all_reduce(t, group=group)
                 total_nnz = int(t.cpu()[0])
         self.nnz = int(total_nnz)
-        # every rank's slab boundaries (global row ids), [world x slabs+1]
-        mine = torch.from_numpy(self.u_sub + self.ulo).to(self.U.device)
+        # every rank's slab boundaries (global row ids), [world x slabs+1], and the staging
+        # buffers of the slab gathers (allocated once: nothing is allocated inside a sweep)
+        self.u_sub_all = self._exchange_bounds(self.u_sub + self.ulo)
+        self.i_sub_all = self._exchange_bounds(self.i_sub + self.ilo)
+        self._stage_u = self._make_stages(self.u_sub_all, self.U)
+        self._stage_i = self._make_stages(self.i_sub_all, self.V)
+
+    def _exchange_bounds(self, mine_np):
+        mine = torch.from_numpy(np.ascontiguousarray(mine_np)).to(self.U.device)
         if self.world > 1:
             import torch.distributed as dist
             every = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
-            dist.all_gather_into_tensor(every, mine, group=group)
-            self.u_sub_all = every.cpu().numpy().reshape(self.world, -1)
-        else:
-            self.u_sub_all = mine.cpu().numpy().reshape(1, -1)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            return every.cpu().numpy().reshape(self.world, -1)
+        return mine.cpu().numpy().reshape(1, -1)
+
+    def _make_stages(self, sub_all, table):
+        """Per slab: (send [width x ld], recv [world*width x ld]) with width = the longest
+        rank's slab; None on a single rank."""
+        if self.world == 1:
+            return None
+        out = []
+        for s in range(sub_all.shape[1] - 1):
+            width = int((sub_all[:, s + 1] - sub_all[:, s]).max())
+            out.append((torch.zeros((width, table.shape[1]), dtype=table.dtype,
+                                    device=table.device),
+                        torch.empty((self.world * width, table.shape[1]), dtype=table.dtype,
+                                    device=table.device)))
+        return out
 
     @classmethod
     def from_global(cls, indptr, indices, vals, shape, rank, alpha, dtype=np.float64,
-                    group=None, backend=None, chunk=0, user_slabs=None):
+                    group=None, backend=None, chunk=0, user_slabs=None, item_slabs=None):
         """Every rank is given the whole CSR (host arrays or device tensors).  The CSC is
         built on the device (the reference re-runs scipy's csr_tocsc per item,
         src/als.py:268-280), both are cut into per-rank row ranges balanced by stored
@@ -157,7 +184,7 @@ class AlsEngine(object):
         csc = (cptr_h[ib[me]:ib[me + 1] + 1] - a, cidx[a:z], cval[a:z])
         return cls(csr, csc, (n, m), rank, alpha, dtype=dtype, user_bounds=ub, item_bounds=ib,
                    group=group, backend=backend, chunk=chunk, total_nnz=int(ptr_h[-1]),
-                   user_slabs=user_slabs)
+                   user_slabs=user_slabs, item_slabs=item_slabs)
 
     # ---- factors ------------------------------------------------------------
     def set_factors(self, user_feats, item_feats):
@@ -194,71 +221,83 @@ class AlsEngine(object):
                 table[int(bounds[r]):int(bounds[r + 1])].copy_(
                     recv[r * width:r * width + int(sizes[r])])
 
-    def _start_slab_gather(self, table, s):
-        """Begin the all-gather of user slab s (rows u_sub_all[r, s:s+2] of every rank r) and
-        return what `_finish_slab_gather` needs.  The collective is ordered after the kernels
-        already enqueued on the current stream and runs beside the ones enqueued later."""
+    def _start_slab_gather(self, table, sub_all, stages, s, src=None):
+        """Begin the all-gather of slab s (rows sub_all[r, s:s+2] of every rank r) into
+        `table` and return what `_finish_slab_gather` needs.  This rank's rows are taken
+        from `src` (a table indexed like `table`; default `table` itself).  The collective
+        is ordered after the kernels already enqueued on the current stream and runs beside
+        the ones enqueued later."""
         import torch.distributed as dist
-        lo = self.u_sub_all[:, s]
-        sizes = self.u_sub_all[:, s + 1] - lo
+        lo = sub_all[:, s]
+        sizes = sub_all[:, s + 1] - lo
         width = int(sizes.max())
-        send = torch.zeros((width, table.shape[1]), dtype=table.dtype, device=table.device)
-        mlo = int(lo[self.me])
-        send[:int(sizes[self.me])].copy_(table[mlo:mlo + int(sizes[self.me])])
-        recv = torch.empty((self.world * width, table.shape[1]), dtype=table.dtype,
-                           device=table.device)
-        # asynchronous where that is the backend's normal mode (RCCL; gloo on host tensors);
-        # gloo with device tensors does not complete an asynchronous gather
+        send, recv = stages[s]
+        mlo, mine = int(lo[self.me]), int(sizes[self.me])
+        send[:mine].copy_((table if src is None else src)[mlo:mlo + mine])
+        # asynchronous where that is the backend's normal mode (RCCL; gloo on host tensors).
+        # gloo with device tensors (several ranks rehearsing on one GPU) is unreliable:
+        # that case goes through host copies, blocking.
         overlap = dist.get_backend(self.group) == 'nccl' or not table.is_cuda
-        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=overlap)
-        return (work if overlap else None), recv, send, lo, sizes, width
+        if overlap:
+            work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        else:
+            work = None
+            host = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
+            recv.copy_(host)
+        return work, recv, lo, sizes, width
 
-    def _finish_slab_gather(self, table, pending):
-        work, recv, _send, lo, sizes, width = pending
+    def _finish_slab_gather(self, table, pending, include_me=False):
+        work, recv, lo, sizes, width = pending
         if work is not None:
             work.wait()
         for r in range(self.world):
-            if r != self.me and sizes[r]:
+            if (include_me or r != self.me) and sizes[r]:
                 table[int(lo[r]):int(lo[r] + sizes[r])].copy_(
                     recv[r * width:r * width + int(sizes[r])])
 
     # ---- the loop body ------------------------------------------------------
-    def _user_half(self, cur, dst, table, want_err):
-        """Solve every slab of this rank's users into `dst` (local rows); when `table` is
-        given, gather each finished slab into it while the next one is computed.  Returns
-        the squared error of `cur` (local part, device tensor) or None."""
+    def half_sweep_users(self):
+        self._user_half(None, self.U, False)
+
+    def _user_half(self, cur, dst_table, want_err):
+        mine = slice(self.ulo, self.uhi)
+        return self._half_local(self.plans_u, self.V, cur, dst_table, mine, self.u_sub_all,
+                                self._stage_u, want_err)
+
+    def _half_local(self, plans, src, cur, dst_table, mine, sub_all, stages, want_err):
+        """The plans index this rank's rows from 0, the gathers index whole tables."""
         sse = None
         pending = []
-        for s, plan in enumerate(self.plans_u):
+        dst_local = dst_table[mine]
+        for s, plan in enumerate(plans):
             if want_err:
-                part = plan.half_sweep_err(self.V, cur, dst, self.alpha)
+                part = plan.half_sweep_err(src, cur, dst_local, self.alpha)
                 sse = part if sse is None else sse + part
             else:
-                plan.half_sweep(self.V, dst, self.alpha)
-            if table is not None and self.world > 1:
-                pending.append(self._start_slab_gather(table, s))
+                plan.half_sweep(src, dst_local, self.alpha)
+            if self.world > 1:
+                pending.append(self._start_slab_gather(dst_table, sub_all, stages, s))
         for p in pending:
-            self._finish_slab_gather(table, p)
+            self._finish_slab_gather(dst_table, p)
         return sse
-
-    def half_sweep_users(self):
-        self._user_half(None, self.U[self.ulo:self.uhi], self.U, False)
 
     def half_sweep_users_err(self, keep_old=False):
         """The user half-sweep, which also gives the squared training error of the
         factors as they are BEFORE it (the error the reference computes at the end of the
         previous sweep, src/als.py:161-165) at no extra pass over the ratings.  Returns the
-        all-reduced 1-element fp64 device tensor.  With keep_old the new rows are parked
-        in a side table until ``commit_users()`` (or dropped by ``discard_users()``), so
-        a caller that decides to stop on that error still holds the factors it belongs to."""
-        mine = self.U[self.ulo:self.uhi]
+        all-reduced 1-element fp64 device tensor.  With keep_old the new rows go to a second
+        full-size table (their slab gathers included) until ``commit_users()`` swaps it in
+        (or ``discard_users()`` drops it), so a caller that decides to stop on that error
+        still holds the factors it belongs to."""
+        cur = self.U[self.ulo:self.uhi]
         if keep_old:
             if self._U_next is None:
-                self._U_next = torch.zeros_like(mine)
-            sse = self._user_half(mine, self._U_next, None, True)
+                self._U_next = torch.zeros_like(self.U)
+            sse = self._user_half(cur, self._U_next, True)
             self._pending = True
         else:
-            sse = self._user_half(mine, mine, self.U, True)
+            sse = self._user_half(cur, self.U, True)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(sse, group=self.group)
@@ -267,16 +306,17 @@ class AlsEngine(object):
     def commit_users(self):
         if not self._pending:
             raise RuntimeError('no parked user half-sweep to commit')
-        self.U[self.ulo:self.uhi].copy_(self._U_next)
+        # the parked table is complete on every rank (its slabs were gathered as they were
+        # computed): it becomes the user table, the old one the next parking space
+        self.U, self._U_next = self._U_next, self.U
         self._pending = False
-        self._all_gather_rows(self.U, self.user_bounds)
 
     def discard_users(self):
         self._pending = False
 
     def half_sweep_items(self):
-        self.plan_i.half_sweep(self.U, self.V[self.ilo:self.ihi], self.alpha)
-        self._all_gather_rows(self.V, self.item_bounds)
+        self._half_local(self.plans_i, self.U, None, self.V, slice(self.ilo, self.ihi),
+                         self.i_sub_all, self._stage_i, False)
 
     def train_sse_async(self):
         """Sum of squared errors over all stored entries as a 1-element fp64 device

@@ -80,34 +80,73 @@ def csr_from_sorted(rows, n_rows):
     return indptr
 
 
-def sharded_problem(seed, n_users_per_block, n_items, nnz_per_block, world, me, device):
-    """Weak-scaling problem of `world` user blocks: this rank's CSR slice (its own
-    block) and CSC slice (its item range over every block).
+def item_bounds_by_popularity(seed, n_items, parts, device, item_shift=60.0):
+    """Contiguous item-id ranges with (almost) equal EXPECTED numbers of entries: an item's
+    share of the entries is its popularity weight 1/(rank + item_shift), the ranks scattered
+    over the ids by the seed's permutation (see user_block), so every rank derives the same
+    bounds without seeing the other ranks' blocks.  int64 array of parts+1 item ids."""
+    gi = torch.Generator(device=device)
+    gi.manual_seed(int(seed) * 1000003)
+    perm = torch.randperm(n_items, generator=gi, device=device)
+    w_rank = 1.0 / (torch.arange(n_items, dtype=torch.float64, device=device) + item_shift)
+    w_id = torch.empty_like(w_rank)
+    w_id[perm] = w_rank                      # weight of item id perm[rank]
+    cum = torch.cumsum(w_id, 0)
+    targets = cum[-1] * torch.arange(1, parts, dtype=torch.float64, device=device) / parts
+    cuts = torch.searchsorted(cum, targets).cpu().numpy().astype(np.int64)
+    bounds = np.concatenate(([0], cuts, [n_items])).astype(np.int64)
+    return np.maximum.accumulate(np.minimum(bounds, n_items))
+
+
+def sharded_problem(seed, n_users_per_block, n_items, nnz_per_block, world, me, device,
+                    n_blocks=None):
+    """A problem of `n_blocks` user blocks (default `world`: weak scaling, one block per
+    rank; a fixed n_blocks that `world` divides: strong scaling, n_blocks/world consecutive
+    blocks per rank): this rank's CSR slice (its own blocks) and CSC slice (its item range,
+    cut by expected entries, over every block).
 
     Returns dict(shape, csr, csc, user_bounds, item_bounds, total_nnz); csr/csc are
     (indptr int64, indices int32, vals float32) device tensors with LOCAL row ids and
     GLOBAL column ids."""
     n0, m = int(n_users_per_block), int(n_items)
-    item_bounds = (np.arange(world + 1, dtype=np.int64) * m) // world
+    n_blocks = int(world if n_blocks is None else n_blocks)
+    if n_blocks % world:
+        raise ValueError('the number of ranks (%d) must divide the number of blocks (%d)'
+                         % (world, n_blocks))
+    per = n_blocks // world
+    item_bounds = item_bounds_by_popularity(seed, m, world, device) if world > 1 else \
+        np.array([0, m], dtype=np.int64)
     ilo, ihi = int(item_bounds[me]), int(item_bounds[me + 1])
-    csr = None
+    r_users, r_items, r_vals = [], [], []
     c_items, c_users, c_vals = [], [], []
-    for b in range(world):
+    for b in range(n_blocks):
         users, items, vals = user_block(seed, b, n0, m, nnz_per_block, device)
-        if b == me:
-            csr = (csr_from_sorted(users, n0), items.to(torch.int32), vals)
-        sel = (items >= ilo) & (items < ihi)
-        c_items.append(items[sel] - ilo)
-        c_users.append(users[sel] + b * n0)
+        if me * per <= b < (me + 1) * per:
+            r_users.append(users + (b - me * per) * n0)
+            r_items.append(items.to(torch.int32))
+            r_vals.append(vals)
+        if world == 1:
+            sel = slice(None)
+            c_items.append(items.to(torch.int32))
+        else:
+            sel = (items >= ilo) & (items < ihi)
+            c_items.append((items[sel] - ilo).to(torch.int32))
+        c_users.append((users[sel] + b * n0).to(torch.int32))
         c_vals.append(vals[sel])
         del users, items, vals, sel
+    csr = (csr_from_sorted(torch.cat(r_users), n0 * per), torch.cat(r_items), torch.cat(r_vals))
+    del r_users, r_items, r_vals
     ci, cu, cv = torch.cat(c_items), torch.cat(c_users), torch.cat(c_vals)
-    order = torch.argsort(ci * (n0 * world) + cu)
-    ci, cu, cv = ci[order], cu[order], cv[order]
-    csc = (csr_from_sorted(ci, ihi - ilo), cu.to(torch.int32), cv)
-    return dict(shape=(n0 * world, m), csr=csr, csc=csc,
-                user_bounds=np.arange(world + 1, dtype=np.int64) * n0,
-                item_bounds=item_bounds, total_nnz=int(nnz_per_block) * world)
+    del c_items, c_users, c_vals
+    # stable sort by item keeps the users of an item ascending (the blocks were appended in
+    # user order)
+    ci, order = torch.sort(ci.to(torch.int64), stable=True)
+    cu, cv = cu[order], cv[order]
+    del order
+    csc = (csr_from_sorted(ci, ihi - ilo), cu, cv)
+    return dict(shape=(n0 * n_blocks, m), csr=csr, csc=csc,
+                user_bounds=np.arange(world + 1, dtype=np.int64) * (n0 * per),
+                item_bounds=item_bounds, total_nnz=int(nnz_per_block) * n_blocks)
 
 
 def init_factors(seed, rank, n_items, item_sums, item_counts):

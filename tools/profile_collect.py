@@ -1,75 +1,137 @@
 #!/usr/bin/env python3
-"""gpurun_out/<tag>/ (written by tools/profile_round.sh) -> the committed profiles/ files:
-bench line, kernel stats, the PMC CSVs restricted to the library's kernels, and traffic.json
-(HBM bytes per half-sweep launch: FETCH_SIZE in KB, doubled as gfx950 requires, + WRITE_SIZE KB).
-usage: tools/profile_collect.py <tag>"""
+"""gpurun_out/<tag>_<config>_<dtype>/ (written by tools/profile_round.sh) -> the committed
+profiles/ files: bench line, kernel stats, the PMC CSVs restricted to the library's kernels,
+and profiles/<tag>_summary.json, the one-screen digest bench.py reads back:
+per configuration and per side of the sweep the HBM bytes of one half-sweep launch (FETCH_SIZE
+in KB, doubled as gfx950 requires for wide coalesced reads, + WRITE_SIZE KB), the MFMA
+utilisation (SQ_VALU_MFMA_BUSY_CYCLES over SIMD cycles) and the kernels' average times, stamped
+with the commit and a hash of the kernel sources they were measured on.
+usage: tools/profile_collect.py <tag> <config>[/<dtype>] [<config>[/<dtype>] ...]"""
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
+import subprocess
 import sys
 from collections import defaultdict
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, 'gpurun_out', tag)
 dst = os.path.join(root, 'profiles')
-shutil.copy(os.path.join(src, 'bench_c2.json'), os.path.join(dst, '%s_bench_c2.json' % tag))
-shutil.copy(os.path.join(src, 'stats', 'c2_kernel_stats.csv'),
-            os.path.join(dst, '%s_bench_c2_kernel_stats.csv' % tag))
+HALF = ('max_abs', 'gram_chunks', 'sum_slabs', 'solve_rows', 'sum_err')
+N_SIMD = 1024  # 256 CUs x 4
 
 
-def rows_of(name):
-    path = glob.glob(os.path.join(src, name, '*counter_collection.csv'))[0]
+def source_sha():
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(root, 'recommendation-models_amd', 'csrc', '*.h*'))):
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def rows_of(src, name):
+    path = glob.glob(os.path.join(src, name, '**', '*counter_collection.csv'), recursive=True)[0]
     return [r for r in csv.DictReader(open(path)) if 'alsmi::' in r['Kernel_Name']]
 
 
-for name, out in (('pmc_fetch_size', 'fetch_size'), ('pmc_write_size', 'write_size'),
-                  ('pmc_sq_waves', 'sq_issue'), ('pmc_sq_wave_cycles', 'sq_wait')):
-    rows = rows_of(name)
-    with open(os.path.join(dst, '%s_bench_c2_pmc_%s.csv' % (tag, out)), 'w', newline='') as f:
-        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-        w.writeheader()
-        w.writerows(rows)
-
-
-def per_launch(name, counter):
-    """Sum of `counter` over the kernels of one half-sweep, split by side: a half-sweep is the
-    run of dispatches that ends with a solve_rows kernel; the user side is the ERR variant."""
-    sides = defaultdict(list)
-    run = 0.0
-    rows = [r for r in rows_of(name) if r['Counter_Name'] == counter]
+def launches(rows, counter):
+    """Per side the list of per-launch sums of `counter`: a half-sweep launch is the run of
+    dispatches that starts with max_abs_kernel (fp32) or with the first chunk / solve kernel
+    after a sum_err / solve kernel of another kind; the user side is the one whose kernels are
+    the error-summing variants."""
+    rows = [r for r in rows if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    sides = defaultdict(list)
+    cur, is_user, seen_solve = 0.0, False, False
+
+    def close():
+        nonlocal cur, is_user, seen_solve
+        if seen_solve:
+            sides['user_side' if is_user else 'item_side'].append(cur)
+        cur, is_user, seen_solve = 0.0, False, False
+
     for r in rows:
         k = r['Kernel_Name']
-        if not any(s in k for s in ('gram_chunks', 'sum_slabs', 'solve_rows', 'max_abs', 'sum_err')):
+        if not any(s in k for s in HALF):
             continue
-        run += float(r['Counter_Value'])
+        head = k.split('(')[0]
+        starts = 'max_abs' in k or (seen_solve and ('gram_chunks' in k or
+                                                    ('solve_rows_kernel' in k)))
+        if starts:
+            close()
+        cur += float(r['Counter_Value'])
         if 'solve_rows' in k:
-            side = 'user_side' if ', true>' in k.split('(')[0] else 'item_side'
-            sides[side].append(run)
-            run = 0.0
-        if 'sum_err' in k and sides['user_side']:
-            sides['user_side'][-1] += float(r['Counter_Value'])
-            run = 0.0
-    return {s: sum(v) / len(v) for s, v in sides.items()}
+            seen_solve = True
+            if head.rstrip().endswith('true>'):
+                is_user = True
+        if 'sum_err' in k:
+            is_user = True
+    close()
+    return {s: sum(v) / len(v) for s, v in sides.items() if v}
 
 
-fetch = per_launch('pmc_fetch_size', 'FETCH_SIZE')
-write = per_launch('pmc_write_size', 'WRITE_SIZE')
-traffic = {
-    'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py '
-              '--steps 3 --warmup 1 --cpu-frac 0 (config c2, f32); tools/profile_round.sh',
-    'units': 'counters are KB; FETCH_SIZE doubled (gfx950 reports half the bytes of wide '
-             'coalesced reads), WRITE_SIZE as is; per half-sweep launch = max_abs + gram_chunks '
-             '+ sum_slabs + solve_rows (+ sum_err on the user side)',
-}
-total = 0.0
-for side in ('user_side', 'item_side'):
-    f, w = fetch[side] * 1024.0, write[side] * 1024.0
-    traffic[side] = {'fetch_size_raw_bytes': f, 'write_size_bytes': w, 'hbm_bytes': 2 * f + w}
-    total += 2 * f + w
-traffic['half_sweep_hbm_bytes_per_launch'] = total / 2
-json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
-print(json.dumps(traffic, indent=1))
+def collect(spec):
+    config, _, dtype = spec.partition('/')
+    dtype = dtype or 'float32'
+    src = os.path.join(root, 'gpurun_out', '%s_%s_%s' % (tag, config, dtype))
+    stem = '%s_bench_%s%s' % (tag, config, '' if dtype == 'float32' else '_f64')
+    shutil.copy(os.path.join(src, 'bench.json'), os.path.join(dst, stem + '.json'))
+    stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)[0]
+    shutil.copy(stats, os.path.join(dst, stem + '_kernel_stats.csv'))
+    for name, out in (('pmc_fetch_size', 'fetch_size'), ('pmc_write_size', 'write_size'),
+                      ('pmc_sq_waves', 'sq_issue'), ('pmc_sq_wave_cycles', 'sq_wait')):
+        rows = rows_of(src, name)
+        with open(os.path.join(dst, '%s_pmc_%s.csv' % (stem, out)), 'w', newline='') as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+    fetch = launches(rows_of(src, 'pmc_fetch_size'), 'FETCH_SIZE')
+    write = launches(rows_of(src, 'pmc_write_size'), 'WRITE_SIZE')
+    issue = rows_of(src, 'pmc_sq_waves')
+    busy = launches(issue, 'SQ_VALU_MFMA_BUSY_CYCLES')
+    gui = launches(issue, 'GRBM_GUI_ACTIVE')
+    entry = {}
+    for side in ('user_side', 'item_side'):
+        f, w = fetch[side] * 1024.0, write[side] * 1024.0
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        cycles = gui[side] / 8.0
+        entry[side] = {'fetch_size_raw_bytes': f, 'write_size_bytes': w, 'hbm_bytes': 2 * f + w,
+                       'mfma_busy_cycles': busy[side], 'gpu_cycles': cycles,
+                       'mfma_util': busy[side] / (cycles * N_SIMD)}
+    kern = {}
+    for r in csv.DictReader(open(stats)):
+        if 'alsmi::' in r['Name']:
+            kern[r['Name'].split('(')[0].replace('void ', '')] = {
+                'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3}
+    entry['kernels'] = kern
+    entry['bench_ms_per_step'] = json.loads(
+        open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])['ms_per_step']
+    return '%s/%s' % (config, dtype), entry
+
+
+def main():
+    path = os.path.join(dst, '%s_summary.json' % tag)
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc.update({
+        'commit': subprocess.check_output(['git', '-C', root, 'rev-parse', '--short', 'HEAD'],
+                                          text=True).strip(),
+        'kernel_source_sha': source_sha(),
+        'source': 'tools/profile_round.sh: rocprofv3 --kernel-trace --stats and four separate '
+                  '--pmc passes (FETCH_SIZE; WRITE_SIZE; two SQ sets) of bench.py',
+        'units': 'FETCH_SIZE / WRITE_SIZE are KB; hbm_bytes = 2 x FETCH_SIZE (gfx950 reports half '
+                 'the bytes of wide coalesced reads) + WRITE_SIZE, per half-sweep launch; '
+                 'mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)',
+    })
+    doc.setdefault('configs', {})
+    for spec in sys.argv[2:]:
+        key, entry = collect(spec)
+        doc['configs'][key] = entry
+        print(key, json.dumps({s: {k: entry[s][k] for k in ('hbm_bytes', 'mfma_util')}
+                               for s in ('user_side', 'item_side')}))
+    json.dump(doc, open(path, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
