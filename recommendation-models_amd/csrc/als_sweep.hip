@@ -529,15 +529,13 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
     }
 }
 
-// fp32 data goes to the 16-bit matrix cores (at padded rank 128 with one wave per SIMD: 36
-// accumulator tiles in the accumulation registers, the operand sets in the others); fp64 keeps
-// its own MFMA.  The debug dump of the normal equations wants unscaled accumulators and takes
-// the bf16 split up to padded rank 64, the native MFMA above.  ABLATE 4 / 10 force the native MFMA / the bf16 split
-// (timing comparisons).
+// fp32 data goes to the 16-bit matrix cores; fp64 keeps its own MFMA.  The debug dump of the
+// normal equations accumulates exactly as the half-sweep does and undoes the power-of-two
+// scale afterwards, so that it shows what production solves.  ABLATE 4 / 10 force the native
+// MFMA / the bf16 split (timing comparisons).
 template <typename T, int NV, int ABLATE, bool DUMP>
 constexpr int gram_mode() {
     if (sizeof(T) != 4 || NV > 8 || ABLATE == 4) return GRAM_NATIVE;
-    if (DUMP) return NV <= 4 ? GRAM_BF16X3 : GRAM_NATIVE;
     if (ABLATE == 20) return GRAM_F16X2_WIDE;
     return ABLATE == 10 ? GRAM_BF16X3 : GRAM_F16X2;
 }
@@ -1256,7 +1254,10 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             __builtin_amdgcn_wave_barrier();
             *lane_err_slot += row_error_part<T, NV>(G, E.sum, Asm, lane, inv_s2);
         }
-        if constexpr (is_f16x2(MODE)) {  // (S^2 A) x = S^2 b
+        if constexpr (is_f16x2(MODE) && DUMP) {  // show the unscaled system (exact: S^2 = 2^k)
+#pragma unroll
+            for (int k = 0; k < Gram<T, NV>::NTRI; ++k) G.acc[k] *= inv_s2;
+        } else if constexpr (is_f16x2(MODE)) {  // (S^2 A) x = S^2 b
 #pragma unroll
             for (int e = 0; e < NV; ++e) G.b[e] *= s2;
         }
@@ -1268,7 +1269,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             if (lane < KP) out[lane] = sum;
             continue;
         }
-        const T ridge = p.alpha * (T)(end - beg) * s2;
+        const T ridge = p.alpha * (T)(end - beg) * (DUMP ? T(1) : s2);
         if constexpr (FAST && sizeof(T) == 4) {
             float xs[NV];
             float *stash = nullptr;
@@ -1668,7 +1669,7 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     const bool dump = A_out != nullptr;
     int mode = GRAM_NATIVE;
     if constexpr (sizeof(T) == 4 && NV <= 8) {
-        mode = dump ? (NV <= 4 ? GRAM_BF16X3 : GRAM_NATIVE) : GRAM_F16X2;
+        mode = GRAM_F16X2;  // the dump included: it accumulates as the half-sweep does
         if constexpr (NV == 4) {
             if (!dump && !err_out && ablation() == 4) mode = GRAM_NATIVE;
             if (!dump && !err_out && ablation() == 10) mode = GRAM_BF16X3;
@@ -1680,7 +1681,11 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
                 ALSMI_REQUIRE(NV == 8,
                               "half-sweep: an fp32 source table of %lld rows at padded rank %d "
                               "exceeds 4 GiB", (long long)n_src, NV * 16);
-                mode = GRAM_F16X2_WIDE;
+                if (!dump)
+                    mode = GRAM_F16X2_WIDE;
+                else
+                    ALSMI_REQUIRE(n_src * (int64_t)(NV * 16) * 4 <= (int64_t)UINT32_MAX,
+                                  "alsmi_normal_equations: source table above 4 GiB");
             }
             // scale of the fp16 split: the largest magnitude of the source table
             ALSMI_HIP_CHECK(hipMemsetAsync(pl->max_bits, 0, sizeof(unsigned), st));

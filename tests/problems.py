@@ -13,8 +13,9 @@ def random_problem(seed, n, m, nnz, rank, levels=(1, 2, 3, 4, 5), empty_rows=(),
     if long_row is not None:
         r, length = long_row
         extra = rng.choice(m, size=length, replace=False)
-        users = np.concatenate([users[users != r], np.full(length, r)])
-        items = np.concatenate([items[:users.size - length], extra])
+        keep_other = users != r
+        users = np.concatenate([users[keep_other], np.full(length, r)])
+        items = np.concatenate([items[keep_other], extra])
     keep = ~(np.isin(users, empty_rows) | np.isin(items, empty_cols))
     users, items = users[keep], items[keep]
     order = np.lexsort((items, users))

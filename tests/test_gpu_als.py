@@ -177,6 +177,46 @@ def test_fp32_half_sweep_any_factor_magnitude(gpu, scale):
     plan.close()
 
 
+def test_fp32_half_sweep_one_tiny_dimension(gpu):
+    """What "elements below max * 2^-16 lose precision relative to themselves" means for the
+    solved vector: one factor DIMENSION uniformly 2^-20 of the others.  Its low fp16 half falls
+    into the subnormal range, so its Gram entries keep about 17 instead of 24 bits; the ridge
+    dominates that dimension's equation, the vector as a whole stays within the fp32 bar and
+    the tiny dimension's own components within 1e-4 (median) / 1e-3 (over all rows, in norm) of
+    their values."""
+    device, torch = gpu
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    rank = 64
+    P = random_problem(33, 300, 400, 20000, rank)
+    Vs = P['V'].copy()
+    Vs[5, :] *= 2.0 ** -20
+    side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], 300, 400, 'float32', device)
+    plan = dev.SweepPlan(side, rank)
+    V = dev.factors_to_device(Vs, 'float32', device)
+    U = V.new_zeros((300, dev.padded_rank(rank)))
+    plan.half_sweep(V, U, 0.1)
+    got = dev.factors_to_host(U, rank)
+    want = ao.half_sweep(P['indptr'], P['indices'], P['vals'], dev.factors_to_host(V, rank), rank,
+                         0.1)
+    assert col_rel_err(got, want) < 1e-4
+    comp = np.abs(got[5] - want[5]) / np.maximum(np.abs(want[5]), 1e-30)
+    across = np.linalg.norm(got[5] - want[5]) / np.linalg.norm(want[5])
+    assert np.median(comp) < 1e-4 and across < 1e-3, (np.median(comp), across)
+    # the normal equations the kernel shows are the ones production accumulates (fp16 split):
+    # row / column 5 of the Gram matrix to 2^-16 of its own size, the rest to fp32 level
+    A, _ = plan.normal_equations(V, 0.1)
+    A = A.cpu().numpy().astype(np.float64)
+    Vq = dev.factors_to_host(V, rank)
+    lo, hi = P['indptr'][7], P['indptr'][8]
+    S = Vq[:, P['indices'][lo:hi]]
+    Aref = S.dot(S.T) + 0.1 * (hi - lo) * np.eye(rank)
+    others = np.delete(np.arange(rank), 5)
+    assert rel_err(A[7][np.ix_(others, others)], Aref[np.ix_(others, others)]) < 2e-6
+    assert rel_err(A[7][5, others], Aref[5, others]) < 2.0 ** -14
+    plan.close()
+
+
 def test_fp32_half_sweep_zero_source_table(gpu):
     """An all-zero source table (largest magnitude 0) with a positive ridge: zero solution."""
     device, torch = gpu
