@@ -76,6 +76,7 @@ class ALS(BaseEstimator):
         _ = self.data  # pickles carry the host matrix, never device tensors
         state = dict(self.__dict__)
         state.pop('_data_dev', None)
+        state.pop('_tables', None)
         return state
 
     def _build_data(self, X, y, shape):
@@ -142,8 +143,26 @@ class ALS(BaseEstimator):
         self.rmse_history_ = []
         nnz = engine.nnz
 
-        def to_rmse(sse):
-            return float(np.sqrt(float(sse.cpu()[0]) / nnz)) if nnz else float('nan')
+        sum_sq = None
+
+        def to_rmse(sse, recheck=False):
+            """sqrt(sse / nnz).  The fused error is a difference of three sums (sum r^2 -
+            2 u.b + u^T G u); in float32 on a near-exact fit they cancel to rounding noise,
+            possibly below zero.  When it falls under 1e-5 of sum r^2 and the factors it
+            belongs to are still in place (`recheck`), the standalone pass (fp64 accumulation
+            of per-entry residuals) replaces it; otherwise it is clamped at zero."""
+            nonlocal sum_sq
+            if not nnz:
+                return float('nan')
+            value = float(sse.cpu()[0])
+            if self.dtype == 'float32' or np.dtype(self.dtype) == np.float32:
+                if sum_sq is None:
+                    sum_sq = engine.sum_sq_ratings()
+                if value < 1e-5 * sum_sq:
+                    if recheck:
+                        return engine.train_rmse()
+                    value = max(value, 0.0)
+            return float(np.sqrt(max(value, 0.0) / nnz))
 
         def record(new_rmse):
             self.rmse_history_.append(new_rmse)
@@ -160,7 +179,7 @@ class ALS(BaseEstimator):
         while pending:
             if not by_tol and sweeps >= self.max_iter:
                 break
-            new_rmse = to_rmse(engine.half_sweep_users_err(keep_old=by_tol))
+            new_rmse = to_rmse(engine.half_sweep_users_err(keep_old=by_tol), recheck=by_tol)
             record(new_rmse)
             diff = rmse - new_rmse
             rmse = new_rmse
@@ -177,6 +196,9 @@ class ALS(BaseEstimator):
             record(engine.train_rmse())
         self.n_iter_ = sweeps
         self.user_feats, self.item_feats = engine.get_factors()
+        self.shape_ = (n, m)
+        # the device tables stay for predictions (dropped when the host factors change)
+        self._tables = (engine.U, engine.V, id(self.user_feats), id(self.item_feats))
         if dev_pairs is not None and dev_pairs[0].numel() > 0:
             # score(X, y) (src/als.py:169) on the triplets and factor tables still on the device
             du, di, dy = dev_pairs
@@ -199,11 +221,26 @@ class ALS(BaseEstimator):
             raise IndexError('user/item index out of range')
         users = np.where(users < 0, users + n, users).astype(np.int32)
         items = np.where(items < 0, items + m, items).astype(np.int32)
-        U = dev.factors_to_device(self.user_feats, self.dtype, device)
-        V = dev.factors_to_device(self.item_feats, self.dtype, device)
+        tables = self._cached_tables()
+        if tables is None:
+            tables = (dev.factors_to_device(self.user_feats, self.dtype, device),
+                      dev.factors_to_device(self.item_feats, self.dtype, device),
+                      id(self.user_feats), id(self.item_feats))
+            self._tables = tables
+        U, V = tables[:2]
         pred, _ = dev.sddmm(self.rank, torch.from_numpy(users).to(device),
                             torch.from_numpy(items).to(device), U, V)
         return pred.to(torch.float64).cpu().numpy()
+
+    def _cached_tables(self):
+        """The device copies of the factor tables if they still belong to the host arrays
+        (same array objects, same shapes), else None."""
+        t = getattr(self, '_tables', None)
+        if t is None or t[2] != id(self.user_feats) or t[3] != id(self.item_feats) or \
+                t[0].shape[0] != self.user_feats.shape[1] or \
+                t[1].shape[0] != self.item_feats.shape[1]:
+            return None
+        return t
 
     def _predict(self, X):
         """Predictions for arrays of (user, item) pairs (src/als.py:302-321)."""
@@ -217,8 +254,9 @@ class ALS(BaseEstimator):
 
     def predict_all(self, user):
         """Predictions of every item for one user (src/als.py:347-364)."""
-        users = np.repeat(user, self.data.shape[1])
-        items = np.arange(self.data.shape[1])
+        m = self.item_feats.shape[1]  # (not self.data.shape: that would fetch the ratings)
+        users = np.repeat(user, m)
+        items = np.arange(m)
         return self._predict((users, items))
 
     def score(self, X, y):
@@ -248,10 +286,13 @@ class ALS(BaseEstimator):
         side = dev.SparseSide(np.array([0, row.nnz], dtype=np.int64), row.indices, row.data, 1,
                               self.data.shape[1], self.dtype, device)
         plan = dev.SweepPlan(side, self.rank)
-        V = dev.factors_to_device(self.item_feats, self.dtype, device)
+        tables = self._cached_tables()
+        V = tables[1] if tables is not None else \
+            dev.factors_to_device(self.item_feats, self.dtype, device)
         out = V.new_zeros((1, V.shape[1]))
         plan.half_sweep(V, out, self.alpha)
         self.user_feats[:, user] = dev.factors_to_host(out, self.rank)[:, 0]
+        self._tables = None  # the host factors changed: rebuild the device copy on next use
         plan.close()
 
     def add_user(self):
@@ -262,3 +303,4 @@ class ALS(BaseEstimator):
         self.data = sps.vstack([self.data, sps.csr_matrix((1, shape[1]))], format='csr')
         new_col = np.zeros((self.rank, 1))
         self.user_feats = np.hstack((self.user_feats, new_col))
+        self._tables = None

@@ -330,6 +330,14 @@ class AlsEngine(object):
             dist.all_reduce(sse, group=self.group)
         return sse
 
+    def sum_sq_ratings(self):
+        """Sum of the squared stored ratings over all ranks (a float)."""
+        t = (self.csr.vals.to(torch.float64) ** 2).sum().reshape(1)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.group)
+        return float(t.cpu()[0])
+
     def train_rmse(self):
         sse = float(self.train_sse_async().cpu()[0])
         return float(np.sqrt(sse / self.nnz)) if self.nnz else float('nan')

@@ -394,3 +394,26 @@ def test_als_tol_loop(gpu, golden):
     R = sps.csr_matrix((g['vals'], (g['users'], g['items'])), shape=(n, m))
     als2 = ALS(rank=5, alpha=0.1, tol=0.001, random_state=3).fit((g['users'], g['items']), R)
     np.testing.assert_allclose(als2.item_feats, g['item_feats_sparse'], rtol=1e-8)
+
+
+def test_fp32_tol_loop_on_exactly_low_rank_ratings(gpu):
+    """Ratings that ARE a rank-2 product: the fit becomes near exact, the fused error (a
+    difference of three float32 sums) drops into its rounding noise, and the loop falls back
+    on the standalone pass instead of taking a square root of a negative number."""
+    from alsmi import ALS
+    rng = np.random.default_rng(4)
+    n, m = 400, 300
+    A, B = rng.uniform(0.5, 1.5, (n, 2)), rng.uniform(0.5, 1.5, (m, 2))
+    flat = rng.choice(n * m, size=30000, replace=False)
+    users, items = flat // m, flat % m
+    vals = (A[users] * B[items]).sum(-1)
+    als = ALS(rank=2, alpha=1e-7, tol=1e-7, random_state=3, dtype='float32')
+    als.fit((users, items), vals, shape=(n, m))
+    hist = np.asarray(als.rmse_history_)
+    assert np.isfinite(hist).all() and (hist >= 0).all() and als.n_iter_ >= 3
+    assert hist[-1] < 1e-3 * np.sqrt(np.mean(vals ** 2))
+    # predictions come from the device tables kept by fit; a changed host factor array is seen
+    p0 = als.predict_one(3, 5)
+    np.testing.assert_allclose(p0, als.user_feats[:, 3].dot(als.item_feats[:, 5]), rtol=1e-5)
+    als.user_feats = als.user_feats * 2.0
+    np.testing.assert_allclose(als.predict_one(3, 5), 2.0 * p0, rtol=1e-6)
