@@ -1160,7 +1160,7 @@ struct SolveArgs {
 };
 
 // Rows of at most this many entries are solved in the neighbour-by-neighbour ("dual") form
-// when the padded rank is larger (fp32, padded rank 128).
+// when the padded rank is larger (fp32: up to 64 entries at padded rank 128, up to 48 at 64).
 constexpr int DUAL_MAX_DEG = 64;
 
 // LDS elements one wave needs: the small transposition stage on the fast path (padded rank
@@ -1745,7 +1745,8 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     // output is the KP x KP system itself).  The task list is sorted by length, so each kernel
     // takes a contiguous share; each appends its squared-error partials to the same array.
     bool dual = false;
-    if constexpr (sizeof(T) == 4 && NV == 8) dual = !dump && is_f16x2(mode) && dual_enabled();
+    if constexpr (sizeof(T) == 4 && (NV == 8 || NV == 4))
+        dual = !dump && is_f16x2(mode) && dual_enabled() && (NV == 8 || ablation() == 0);
     int n_err = 0, used = 0;
     a.t_begin = 0;
     a.t_end = dual ? pl->t_dual[0] : pl->n_tasks;
@@ -1753,14 +1754,19 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
                                       &used, st);
     if (rc != ALSMI_OK) return rc;
     n_err += used;
-    if constexpr (sizeof(T) == 4 && NV == 8) {
+    if constexpr (sizeof(T) == 4 && (NV == 8 || NV == 4)) {
         if (dual) {
             for (int k = 0; k < 4; ++k) {
                 a.err_part = pl->err_part + n_err;
                 a.t_begin = pl->t_dual[k];
                 a.t_end = pl->t_dual[k + 1];
                 switch (k) {
-                    case 0: rc = launch_dual<NV, 4>(pl, a, err_out != nullptr, &used, st); break;
+                    case 0:  // (a 64 x 64 neighbour system gains nothing at padded rank 64)
+                        if constexpr (NV == 8)
+                            rc = launch_dual<NV, 4>(pl, a, err_out != nullptr, &used, st);
+                        else
+                            used = 0;
+                        break;
                     case 1: rc = launch_dual<NV, 3>(pl, a, err_out != nullptr, &used, st); break;
                     case 2: rc = launch_dual<NV, 2>(pl, a, err_out != nullptr, &used, st); break;
                     default: rc = launch_dual<NV, 1>(pl, a, err_out != nullptr, &used, st); break;
@@ -1873,9 +1879,10 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     pl->n_chunks = (int)ch_beg.size();
     pl->n_heavy = n_heavy;
     for (int k = 0; k < 5; ++k) pl->t_dual[k] = (int)n;
-    if (dtype == ALSMI_F32 && kp == 128) {
+    if (dtype == ALSMI_F32 && (kp == 128 || kp == 64)) {
         for (int k = 0; k < 4; ++k) {
-            const int64_t deg = alsmi::DUAL_MAX_DEG - 16 * k;
+            // at padded rank 64 the dual form starts at 48 entries (t_dual[0] = t_dual[1])
+            const int64_t deg = alsmi::DUAL_MAX_DEG - 16 * (kp == 64 && k == 0 ? 1 : k);
             pl->t_dual[k] = (int)(std::partition_point(order.begin(), order.end(), [&](int32_t r) {
                                       return indptr_host[r + 1] - indptr_host[r] > deg;
                                   }) - order.begin());
