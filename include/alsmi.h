@@ -133,6 +133,19 @@ int alsmi_sddmm_noalloc(int dtype, int rank, int64_t n_pairs, const int32_t *use
                         const int32_t *items, const void *row_factors, const void *col_factors,
                         const void *vals, void *pred_out, double *sse_out, void *stream);
 
+/* ---- the k best items of a batch of users: src/als.py:347-364 (predict_all returns one
+ * user's score for every item and leaves the ranking to the caller) -----------------
+ *
+ * For every p < n_sel: the k items i with the largest <user_factors[users[p]],
+ * item_factors[i]>, best first, ties broken by the smaller item id; items_out [n_sel x k]
+ * int32, scores_out [n_sel x k] of dtype.  1 <= k <= min(1024, n_items).  workspace: at least
+ * alsmi_topk_workspace_bytes(dtype, n_sel, n_items) bytes (the dense n_sel x n_items score
+ * block: batch the users accordingly).  Deterministic. */
+size_t alsmi_topk_workspace_bytes(int dtype, int64_t n_sel, int64_t n_items);
+int alsmi_topk_items(int dtype, int rank, int64_t n_sel, const int32_t *users,
+                     const void *user_factors, const void *item_factors, int64_t n_items, int k,
+                     int32_t *items_out, void *scores_out, void *workspace, void *stream);
+
 /* Row index of every stored entry of rows [row_begin,row_end) (the `users`
  * array of data.nonzero(), src/als.py:161), written to rows_out[0 .. nnz_local). */
 int alsmi_expand_rows(const int64_t *indptr, int64_t row_begin, int64_t row_end,

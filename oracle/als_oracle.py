@@ -181,3 +181,12 @@ def als_fit(users, items, y, shape, rank=10, alpha=0.1, tol=0.001, seed=None,
         if history is not None:
             history.append((uf.copy(), itf.copy()))
     return uf, itf, np.array(hist), (indptr, indices, vals)
+
+
+def topk_items(user_feats, item_feats, users, k):
+    """The k best items per user from the dense scores of src/als.py:361-364 (one row of
+    U^T V per user), best first, ties by the smaller item id.  Returns (items, scores)."""
+    scores = user_feats[:, users].T.dot(item_feats)
+    order = np.lexsort((np.broadcast_to(np.arange(scores.shape[1]), scores.shape), -scores),
+                       axis=1)[:, :k]
+    return order, np.take_along_axis(scores, order, axis=1)

@@ -50,6 +50,9 @@ def load():
                                 c_vp, c_vp]),
         'alsmi_sddmm_noalloc': (c_int, [c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_vp, c_vp]),
+        'alsmi_topk_workspace_bytes': (ctypes.c_size_t, [c_int, c_i64, c_i64]),
+        'alsmi_topk_items': (c_int, [c_int, c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp,
+                                     c_vp, c_vp, c_vp]),
         'alsmi_expand_rows': (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
         'alsmi_sparse_workspace_bytes': (ctypes.c_size_t, [c_i64]),
         'alsmi_build_csr': (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -73,7 +76,8 @@ EXPORTS = ('alsmi_version', 'alsmi_last_error', 'alsmi_padded_rank', 'alsmi_plan
            'alsmi_plan_destroy', 'alsmi_plan_info', 'alsmi_half_sweep',
            'alsmi_half_sweep_err',
            'alsmi_normal_equations', 'alsmi_sddmm_workspace_bytes', 'alsmi_sddmm',
-           'alsmi_sddmm_noalloc', 'alsmi_expand_rows', 'alsmi_sparse_workspace_bytes', 'alsmi_build_csr',
+           'alsmi_sddmm_noalloc', 'alsmi_topk_workspace_bytes', 'alsmi_topk_items',
+           'alsmi_expand_rows', 'alsmi_sparse_workspace_bytes', 'alsmi_build_csr',
            'alsmi_csr_to_csc', 'alsmi_imc_padded_width', 'alsmi_imc_workspace_bytes',
            'alsmi_imc_eval')
 

@@ -259,6 +259,24 @@ class ALS(BaseEstimator):
         items = np.arange(m)
         return self._predict((users, items))
 
+    def recommend(self, users, k=10):
+        """The k items with the highest predicted rating for each of `users`: ``(items,
+        scores)`` arrays of shape (len(users), k), best first (ties: smaller item id).
+        The ranking the reference leaves to the caller of ``predict_all``
+        (src/als.py:347-364), done on the device for a batch of users."""
+        check_is_fitted(self, ['item_feats', 'user_feats'])
+        import torch
+        device = dev.require_gpu()
+        users = np.atleast_1d(np.asarray(users)).ravel()
+        n = self.user_feats.shape[1]
+        if users.size and (users.min() < -n or users.max() >= n):
+            raise IndexError('user index out of range')
+        users = np.where(users < 0, users + n, users).astype(np.int32)
+        self._pair_predictions(users[:0], users[:0])  # makes sure the device tables exist
+        U, V = self._cached_tables()[:2]
+        items, scores = dev.topk_items(self.rank, torch.from_numpy(users).to(device), U, V, int(k))
+        return items.cpu().numpy(), scores.to(torch.float64).cpu().numpy()
+
     def score(self, X, y):
         """NEGATIVE root mean squared error on the given pairs (src/als.py:366-388)."""
         check_is_fitted(self, ['item_feats', 'user_feats'])

@@ -298,3 +298,31 @@ def csr_to_csc(indptr, indices, vals, shape):
         _lib.dtype_code(dtype), n, m, nnz, _ptr(indptr), _ptr(indices), _ptr(vals), _ptr(cptr),
         _ptr(cidx), _ptr(cvals), _ptr(ws), _stream()), 'alsmi_csr_to_csc')
     return cptr, cidx, cvals
+
+
+def topk_items(rank, users, row_table, col_table, k, max_workspace_bytes=1 << 30):
+    """The k best items of each user in `users` (int32 device tensor): (items int32 [n x k],
+    scores [n x k]) device tensors, best first, ties by the smaller item id.  The users are
+    processed in batches whose dense score block stays under `max_workspace_bytes`."""
+    lib = _lib.load()
+    device = row_table.device
+    n_sel, n_items = int(users.numel()), int(col_table.shape[0])
+    if users.dtype != torch.int32:
+        raise ValueError('users must be an int32 device tensor')
+    if not 1 <= k <= min(1024, n_items):
+        raise ValueError('k must be between 1 and min(1024, number of items), got %r' % (k,))
+    np_dtype = np.float32 if row_table.dtype == torch.float32 else np.float64
+    code = _lib.dtype_code(np_dtype)
+    items = torch.empty((n_sel, k), dtype=torch.int32, device=device)
+    scores = torch.empty((n_sel, k), dtype=row_table.dtype, device=device)
+    per_user = max(int(lib.alsmi_topk_workspace_bytes(code, 1, n_items)), 1)
+    batch = max(1, min(n_sel, max_workspace_bytes // per_user))
+    ws = torch.empty(int(lib.alsmi_topk_workspace_bytes(code, batch, n_items)) // 8 + 1,
+                     dtype=torch.float64, device=device)
+    for lo in range(0, n_sel, batch):
+        hi = min(n_sel, lo + batch)
+        _lib.check(lib.alsmi_topk_items(code, int(rank), hi - lo, _ptr(users[lo:hi]),
+                                        _ptr(row_table), _ptr(col_table), n_items, int(k),
+                                        _ptr(items[lo:hi]), _ptr(scores[lo:hi]), _ptr(ws),
+                                        _stream()), 'alsmi_topk_items')
+    return items, scores

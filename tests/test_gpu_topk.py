@@ -1,0 +1,69 @@
+"""alsmi_topk_items / ALS.recommend against the ranking of the reference's dense predict_all
+scores (src/als.py:347-364)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('dtype,rank,m,k', [('float64', 10, 517, 10), ('float32', 64, 3000, 100),
+                                             ('float64', 3, 70, 70), ('float32', 128, 1025, 1),
+                                             ('float32', 20, 40000, 1024)])
+def test_topk_items_match_dense_ranking(dtype, rank, m, k):
+    import torch
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    device = dev.require_gpu()
+    rng = np.random.default_rng(rank + m)
+    n = 90
+    U = rng.standard_normal((rank, n))
+    V = rng.standard_normal((rank, m))
+    V[:, 5] = V[:, 3]                       # exact ties between two items
+    V[:, m - 1] = V[:, 3]
+    Ud = dev.factors_to_device(U, dtype, device)
+    Vd = dev.factors_to_device(V, dtype, device)
+    users = rng.integers(0, n, 37).astype(np.int32)
+    # small workspace limit: several batches
+    items, scores = dev.topk_items(rank, torch.from_numpy(users).to(device), Ud, Vd, k,
+                                   max_workspace_bytes=m * 8 * 10)
+    items, scores = items.cpu().numpy(), scores.to(torch.float64).cpu().numpy()
+    Uq, Vq = dev.factors_to_host(Ud, rank), dev.factors_to_host(Vd, rank)
+    want_items, want_scores = ao.topk_items(Uq, Vq, users, k)
+    if dtype == 'float64':
+        # scores to rounding; the ranking can only differ where two scores agree to rounding
+        np.testing.assert_allclose(scores, want_scores, rtol=1e-12, atol=1e-12)
+        differ = items != want_items
+        assert np.abs(scores[differ] - want_scores[differ]).max(initial=0) < 1e-12
+    else:
+        np.testing.assert_allclose(scores, want_scores, rtol=2e-5, atol=2e-5)
+    # properties that hold exactly: sorted best first, ties by item id, no item twice, and the
+    # reported score is the score of the reported item
+    assert (np.diff(scores, axis=1) <= 0).all()
+    tie = np.diff(scores, axis=1) == 0
+    assert (np.diff(items, axis=1)[tie] > 0).all()
+    assert all(np.unique(r).size == k for r in items)
+    dense = Uq[:, users].T.dot(Vq)
+    np.testing.assert_allclose(np.take_along_axis(dense, items.astype(np.int64), axis=1), scores,
+                               rtol=1e-12 if dtype == 'float64' else 2e-5, atol=2e-5)
+    # nothing outside the list beats its last entry
+    for r in range(users.size):
+        rest = np.delete(dense[r], items[r])
+        if rest.size:
+            assert rest.max() <= scores[r, -1] + (1e-12 if dtype == 'float64' else 5e-5)
+
+
+def test_als_recommend(golden):
+    from alsmi import ALS
+    import scipy.sparse as sps
+    R = sps.csr_matrix(np.array([[3.0, 0, 4], [4, 5, 0]]))
+    rows, cols = R.nonzero()
+    als = ALS(2, tol=1e-6, random_state=42).fit((rows, cols), R)
+    items, scores = als.recommend([0, 1, -1], k=2)
+    for u, row, sc in zip((0, 1, 1), items, scores):
+        full = als.predict_all(u)
+        assert list(row) == list(np.argsort(-full, kind='stable')[:2])
+        np.testing.assert_allclose(sc, full[row], rtol=1e-12)
+    with pytest.raises(ValueError):
+        als.recommend([0], k=4)
+    with pytest.raises(IndexError):
+        als.recommend([2], k=1)
