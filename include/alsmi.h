@@ -191,13 +191,23 @@ int alsmi_csr_to_csc(int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
  * the cost (the reference counts it once per sample), lam*Z to the gradient and
  * the scalar lam to every entry of the Hessian-vector product.
  * Calling mode 0 with M = 0 and negated ratings gives X^T diag(r) Y of
- * src/imc.py:157.  1 <= q <= 256. */
+ * src/imc.py:157.  1 <= q <= 256.  n_samples = indptr[n_users] (the host needs it to size
+ * the launch: the pass cuts the ENTRIES, not the users, into equal chunks, so its time does not
+ * depend on how unevenly the entries are spread over the users; every sum has a fixed order). */
 int alsmi_imc_padded_width(int q);
-size_t alsmi_imc_workspace_bytes(int dtype, int64_t n_users, int p, int q);
-int alsmi_imc_eval(int dtype, int mode, int64_t n_users, int p, int q, const int64_t *indptr,
-                   const int32_t *items, const void *ratings, const void *X, const void *Y,
-                   const void *M, void *out, void *pred_out, double *sse_out, void *workspace,
-                   void *stream);
+size_t alsmi_imc_workspace_bytes(int dtype, int64_t n_users, int64_t n_samples, int p, int q);
+int alsmi_imc_eval(int dtype, int mode, int64_t n_users, int64_t n_samples, int p, int q,
+                   const int64_t *indptr, const int32_t *items, const void *ratings, const void *X,
+                   const void *Y, const void *M, void *out, void *pred_out, double *sse_out,
+                   void *workspace, void *stream);
+
+/* table_out [n_rows x alsmi_imc_padded_width(q)] = X [n_rows x p] M [p x q], pad columns zero:
+ * the projected attribute table of the rank-constrained IMC form (Z = U V^T: the rows of Y V
+ * take the place of the item attributes and U that of Z, so the pass over the samples is
+ * n_components wide instead of q wide).  No reference counterpart: the reference validates
+ * n_components and then ignores it (src/imc.py:148-154). */
+int alsmi_imc_project(int dtype, int64_t n_rows, int p, int q, const void *X, const void *M,
+                      void *table_out, void *stream);
 
 #ifdef __cplusplus
 }

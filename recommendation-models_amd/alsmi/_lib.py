@@ -60,9 +60,10 @@ def load():
         'alsmi_csr_to_csc': (c_int, [c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                      c_vp, c_vp, c_vp]),
         'alsmi_imc_padded_width': (c_int, [c_int]),
-        'alsmi_imc_workspace_bytes': (ctypes.c_size_t, [c_int, c_i64, c_int, c_int]),
-        'alsmi_imc_eval': (c_int, [c_int, c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
-                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+        'alsmi_imc_workspace_bytes': (ctypes.c_size_t, [c_int, c_i64, c_i64, c_int, c_int]),
+        'alsmi_imc_eval': (c_int, [c_int, c_int, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp,
+                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+        'alsmi_imc_project': (c_int, [c_int, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -79,7 +80,7 @@ EXPORTS = ('alsmi_version', 'alsmi_last_error', 'alsmi_padded_rank', 'alsmi_plan
            'alsmi_sddmm_noalloc', 'alsmi_topk_workspace_bytes', 'alsmi_topk_items',
            'alsmi_expand_rows', 'alsmi_sparse_workspace_bytes', 'alsmi_build_csr',
            'alsmi_csr_to_csc', 'alsmi_imc_padded_width', 'alsmi_imc_workspace_bytes',
-           'alsmi_imc_eval')
+           'alsmi_imc_eval', 'alsmi_imc_project')
 
 
 def check(status, what):

@@ -146,14 +146,15 @@ class ImcProblem(object):
         torch = self._torch
         self._td = dev.torch_dtype(self.dtype)
         nbytes = int(_lib.load().alsmi_imc_workspace_bytes(
-            _lib.dtype_code(self.dtype), max(self.n_local_users, 1), self.p, self.q))
+            _lib.dtype_code(self.dtype), max(self.n_local_users, 1), self.n_local_samples, self.p,
+            self.q))
         self.workspace = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=self.device)
 
     def _run(self, mode, Md, r, out, local_pred, sse):
         """One pass of the kernels over this rank's samples."""
         _lib.check(_lib.load().alsmi_imc_eval(
-            _lib.dtype_code(self.dtype), int(mode), self.n_local_users, self.p, self.q,
-            dev._ptr(self.indptr), dev._ptr(self.items), dev._ptr(r), dev._ptr(self.X),
+            _lib.dtype_code(self.dtype), int(mode), self.n_local_users, self.n_local_samples,
+            self.p, self.q, dev._ptr(self.indptr), dev._ptr(self.items), dev._ptr(r), dev._ptr(self.X),
             dev._ptr(self.Y), dev._ptr(Md), dev._ptr(out), dev._ptr(local_pred),
             dev._ptr(sse), dev._ptr(self.workspace), dev._stream()), 'alsmi_imc_eval')
 
@@ -191,6 +192,77 @@ class ImcProblem(object):
                 pred_h = np.empty_like(grouped)
                 pred_h[self.order] = grouped
         return out_h, sse_h, pred_h
+
+    # ---- rank-constrained form Z = U V^T (extension; see _fit_low_rank) --------------------
+    def _low_rank_setup(self, r):
+        """Item-major copy of the samples and the workspaces of the r-wide passes."""
+        if getattr(self, '_lr', None) is not None and self._lr['r'] == r:
+            return self._lr
+        torch = self._torch
+        lib = _lib.load()
+        n_items_local = int(self.Y.shape[0])
+        cptr, cidx, cvals = dev.csr_to_csc(self.indptr, self.items, self.ratings,
+                                           (self.n_local_users, n_items_local))
+        ld = lib.alsmi_imc_padded_width(int(r))
+        code = _lib.dtype_code(self.dtype)
+        ws = lambda rows, p: torch.empty(
+            int(lib.alsmi_imc_workspace_bytes(code, max(rows, 1), self.n_local_samples, p, r))
+            // 8 + 1,
+            dtype=torch.float64, device=self.device)
+        self._lr = dict(r=r, ld=ld, cptr=cptr, cidx=cidx, cvals=cvals,
+                        A=torch.zeros((max(self.n_local_users, 1), ld), dtype=self._td,
+                                      device=self.device),
+                        B=torch.zeros((max(n_items_local, 1), ld), dtype=self._td,
+                                      device=self.device),
+                        Yq=self.Y[:, :self.q].contiguous(),
+                        ws_u=ws(self.n_local_users, self.p), ws_i=ws(n_items_local, self.q))
+        return self._lr
+
+    def low_rank_eval(self, U, V):
+        """sum_e (r_e - x_u^T U V^T y_i)^2 and the data parts of its gradients, G V and G^T U
+        with G = X^T diag(pred - r) Y, from two passes over the samples that are r = U.shape[1]
+        wide instead of q wide: user-major against the projected item table Y V, item-major
+        against the projected user table X U."""
+        torch = self._torch
+        lib = _lib.load()
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        V = np.ascontiguousarray(V, dtype=np.float64)
+        r = U.shape[1]
+        if self.n_samples == 0:
+            return 0.0, np.zeros_like(U), np.zeros_like(V)
+        L = self._low_rank_setup(r)
+        code = _lib.dtype_code(self.dtype)
+        Ud = torch.from_numpy(U).to(self.device, self._td)
+        Vd = torch.from_numpy(V).to(self.device, self._td)
+        gU = torch.zeros((self.p, r), dtype=self._td, device=self.device)
+        gV = torch.zeros((self.q, r), dtype=self._td, device=self.device)
+        sse = torch.zeros(1, dtype=torch.float64, device=self.device)
+        if self.n_local_users > 0 and self.n_local_samples > 0:
+            n_items_local = int(self.Y.shape[0])
+            st = dev._stream()
+            _lib.check(lib.alsmi_imc_project(code, self.n_local_users, self.p, r, dev._ptr(self.X),
+                                             dev._ptr(Ud), dev._ptr(L['A']), st),
+                       'alsmi_imc_project')
+            _lib.check(lib.alsmi_imc_project(code, n_items_local, self.q, r, dev._ptr(L['Yq']),
+                                             dev._ptr(Vd), dev._ptr(L['B']), st),
+                       'alsmi_imc_project')
+            _lib.check(lib.alsmi_imc_eval(
+                code, 0, self.n_local_users, self.n_local_samples, self.p, r,
+                dev._ptr(self.indptr),
+                dev._ptr(self.items), dev._ptr(self.ratings), dev._ptr(self.X), dev._ptr(L['B']),
+                dev._ptr(Ud), dev._ptr(gU), None, dev._ptr(sse), dev._ptr(L['ws_u']), st),
+                'alsmi_imc_eval')
+            _lib.check(lib.alsmi_imc_eval(
+                code, 0, n_items_local, self.n_local_samples, self.q, r, dev._ptr(L['cptr']),
+                dev._ptr(L['cidx']),
+                dev._ptr(L['cvals']), dev._ptr(L['Yq']), dev._ptr(L['A']), dev._ptr(Vd),
+                dev._ptr(gV), None, None, dev._ptr(L['ws_i']), st), 'alsmi_imc_eval')
+        if self.group is not None:
+            import torch.distributed as dist
+            for t in (gU, gV, sse):
+                dist.all_reduce(t, group=self.group)
+        return (float(sse.cpu()[0]), gU.to(torch.float64).cpu().numpy(),
+                gV.to(torch.float64).cpu().numpy())
 
     # the three callbacks, with the reference's regulariser terms added on the host
     def cost(self, Z, lam):
@@ -316,7 +388,7 @@ def _fit_low_rank(prob, r, Z, method, alpha, verbose):
         f(U, V) = 0.5 * (sum_e (r_e - x_u^T U V^T y_i)^2 + alpha (||U||^2 + ||V||^2)),
         df/dU = G V + alpha U,   df/dV = G^T U + alpha V,   G = X^T diag(pred - r) Y,
 
-    G coming from the same device evaluation as the full-rank gradient.  Starts from the
+    evaluated by ``ImcProblem.low_rank_eval`` in passes that are r wide, not q wide.  Starts from the
     best rank-r approximation of the reference's initial Z (src/imc.py:157-159) or of the
     given Z.  Returns ``(U V^T, U, V, success, message)``."""
     Z0 = prob.init_z() if Z is None else np.asarray(Z, dtype=np.float64)
@@ -330,9 +402,9 @@ def _fit_low_rank(prob, r, Z, method, alpha, verbose):
 
     def fun(a):
         U, V = unpack(a)
-        G, sse, _ = prob._eval(0, U.dot(V.T), want_sse=True)
+        sse, g_u, g_v = prob.low_rank_eval(U, V)
         f = 0.5 * (sse + alpha * (np.sum(U * U) + np.sum(V * V)))
-        g = np.concatenate(((G.dot(V) + alpha * U).ravel(), (G.T.dot(U) + alpha * V).ravel()))
+        g = np.concatenate(((g_u + alpha * U).ravel(), (g_v + alpha * V).ravel()))
         return f, g
 
     with warnings.catch_warnings():

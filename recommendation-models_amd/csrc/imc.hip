@@ -21,7 +21,6 @@
 namespace alsmi {
 
 constexpr int IMC_MAX_Q = 256;
-constexpr int IMC_SSE_BLOCKS = 2048;
 constexpr int IMC_KSPLIT = 128;
 
 // ---- C[M x N] (+)= op(A) B with one 16x16 tile per wave on v_mfma_*_16x16x4 --------------
@@ -78,11 +77,21 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const T *__restric
     out[i] = s;
 }
 
-// ---- fused SDDMM + SpMM over the entries of each user -----------------------------------------
-// One wave per user row at a time.  mode 0: w = d - r and the squared error is accumulated;
-// mode 1: w = d.
+// ---- fused SDDMM + SpMM over the stored entries ------------------------------------------------
+// The entries (grouped by user through indptr) are cut into CHUNKS OF ENTRIES, not into users:
+// wave c takes entries [c*CH, (c+1)*CH), finds the user its first entry belongs to by a binary
+// search in indptr and walks the users of its range.  A user whose entries lie inside the chunk
+// gets its W row written directly; the part of a user that is cut by a chunk border goes to one
+// of the chunk's two border slots (head: the user began in an earlier chunk; tail: it goes on
+// in the next) and imc_borders_kernel adds the parts of such a user in chunk order.  The work
+// per wave is therefore the same whatever the degree distribution — an item with 60 000
+// ratings (the item-major pass of the rank-constrained form) no longer serialises on one wave —
+// and every sum is formed in a fixed order.  mode 0: w = d - r and the squared error is
+// accumulated; mode 1: w = d.  W must be zero on entry (users without entries keep that).
+constexpr int IMC_CHUNK = 2048;
+
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void imc_rows_kernel(int mode, int64_t n_users,
+__global__ __launch_bounds__(256) void imc_rows_kernel(int mode, int64_t n_users, int64_t n_chunks,
                                                        const int64_t *__restrict__ indptr,
                                                        const int32_t *__restrict__ items,
                                                        const T *__restrict__ ratings,
@@ -90,16 +99,34 @@ __global__ __launch_bounds__(256) void imc_rows_kernel(int mode, int64_t n_users
                                                        const T *__restrict__ Y,
                                                        T *__restrict__ W,
                                                        T *__restrict__ pred_out,
+                                                       T *__restrict__ border,
+                                                       int64_t *__restrict__ border_user,
                                                        double *__restrict__ partials) {
     constexpr int LD = NV * 16;
-    __shared__ double wsum[4];
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
-    const int wl = threadIdx.x >> 6;
-    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int64_t nnz = indptr[n_users];
+    const int64_t c0 = c * IMC_CHUNK;
+    const int64_t c1 = c0 + IMC_CHUNK < nnz ? c0 + IMC_CHUNK : nnz;
+    // the user of entry c0: the last u with indptr[u] <= c0
+    int64_t lo = 0, hi = n_users;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= c0) lo = mid; else hi = mid;
+    }
     double sse = 0.0;
-    for (int64_t u = (int64_t)blockIdx.x * 4 + wl; u < n_users; u += nw) {
-        const int64_t beg = indptr[u], end = indptr[u + 1];
+    // border slots: [c][0] head (user began before c0), [c][1] tail (user goes on after c1)
+    if (lane == 0) {
+        border_user[2 * c] = -1;
+        border_user[2 * c + 1] = -1;
+    }
+    for (int64_t u = lo; u < n_users; ++u) {
+        const int64_t rb = indptr[u], re = indptr[u + 1];
+        if (rb >= c1) break;
+        const int64_t beg = rb > c0 ? rb : c0, end = re < c1 ? re : c1;
+        if (end <= beg) continue;
         T a[NV], wacc[NV];
         load_vec<T, NV>(a, Atab + u * LD + q * NV);
 #pragma unroll
@@ -147,15 +174,42 @@ __global__ __launch_bounds__(256) void imc_rows_kernel(int mode, int64_t n_users
             wacc[e] += __shfl_xor(wacc[e], 16);
             wacc[e] += __shfl_xor(wacc[e], 32);
         }
+        const bool head = rb < c0, tail = re > c1;
+        T *dst = W + u * LD;
+        if (head || tail) {
+            const int slot = head ? 0 : 1;  // (a user that covers the whole chunk is its head)
+            dst = border + (2 * c + slot) * LD;
+            if (lane == 0) border_user[2 * c + slot] = u;
+        }
         if (g == 0) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) W[u * LD + q * NV + e] = wacc[e];
+            for (int e = 0; e < NV; ++e) dst[q * NV + e] = wacc[e];
         }
     }
     sse = wave_sum(sse);
-    if (lane == 0) wsum[wl] = sse;
-    __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (lane == 0) partials[c] = sse;
+}
+
+// Adds the border parts of every user that a chunk border cut, in chunk order: the wave of the
+// chunk where the user's first entry lies (its tail slot, or its head slot for chunk 0 never —
+// a head is by definition not the first part) walks the following chunks' head slots while they
+// belong to the same user.
+template <typename T>
+__global__ __launch_bounds__(256) void imc_borders_kernel(int64_t n_chunks, int ld,
+                                                          const T *__restrict__ border,
+                                                          const int64_t *__restrict__ border_user,
+                                                          T *__restrict__ W) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int64_t u = border_user[2 * c + 1];
+    if (u < 0) return;  // no user leaves this chunk unfinished
+    for (int col = lane; col < ld; col += WAVE) {
+        T sum = border[(2 * c + 1) * ld + col];
+        for (int64_t k = c + 1; k < n_chunks && border_user[2 * k] == u; ++k)
+            sum += border[(2 * k) * ld + col];
+        W[u * ld + col] = sum;
+    }
 }
 
 __global__ __launch_bounds__(256) void imc_sum_sse_kernel(const double *__restrict__ partials,
@@ -183,41 +237,50 @@ static int imc_ld(int q) {
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct ImcWorkspace {
-    size_t a_off, w_off, part_off, sse_off, total;
+    size_t a_off, w_off, part_off, sse_off, border_off, border_user_off, total;
+    int64_t n_chunks;
 };
 
-static ImcWorkspace imc_layout(size_t esz, int64_t n_users, int p, int q) {
+static ImcWorkspace imc_layout(size_t esz, int64_t n_users, int64_t n_samples, int p, int q) {
     ImcWorkspace ws;
     const size_t table = align256((size_t)n_users * imc_ld(q) * esz);
+    ws.n_chunks = (n_samples + IMC_CHUNK - 1) / IMC_CHUNK;
+    if (ws.n_chunks < 1) ws.n_chunks = 1;
     ws.a_off = 0;
     ws.w_off = table;
     ws.part_off = 2 * table;
     ws.sse_off = ws.part_off + align256((size_t)IMC_KSPLIT * p * q * esz);
-    ws.total = ws.sse_off + align256(IMC_SSE_BLOCKS * sizeof(double));
+    ws.border_off = ws.sse_off + align256((size_t)ws.n_chunks * sizeof(double));
+    ws.border_user_off = ws.border_off + align256((size_t)2 * ws.n_chunks * imc_ld(q) * esz);
+    ws.total = ws.border_user_off + align256((size_t)2 * ws.n_chunks * sizeof(int64_t));
     return ws;
 }
 
 template <typename T, int NV>
-static void launch_rows(int grid, int mode, int64_t n_users, const int64_t *indptr,
+static void launch_rows(int64_t n_chunks, int mode, int64_t n_users, const int64_t *indptr,
                         const int32_t *items, const void *ratings, const T *Atab, const void *Y,
-                        T *Wtab, void *pred_out, double *sse_part, hipStream_t st) {
-    hipLaunchKernelGGL((imc_rows_kernel<T, NV>), dim3(grid), dim3(256), 0, st, mode, n_users,
-                       indptr, items, static_cast<const T *>(ratings), Atab,
-                       static_cast<const T *>(Y), Wtab, static_cast<T *>(pred_out), sse_part);
+                        T *Wtab, void *pred_out, T *border, int64_t *border_user,
+                        double *sse_part, hipStream_t st) {
+    hipLaunchKernelGGL((imc_rows_kernel<T, NV>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0,
+                       st, mode, n_users, n_chunks, indptr, items, static_cast<const T *>(ratings),
+                       Atab, static_cast<const T *>(Y), Wtab, static_cast<T *>(pred_out), border,
+                       border_user, sse_part);
 }
 
 template <typename T>
-static int run_imc_eval(int mode, int64_t n_users, int p, int q, const int64_t *indptr,
-                        const int32_t *items, const void *ratings, const void *X, const void *Y,
-                        const void *Mmat, void *out, void *pred_out, double *sse_out,
-                        void *workspace, hipStream_t st) {
+static int run_imc_eval(int mode, int64_t n_users, int64_t n_samples, int p, int q,
+                        const int64_t *indptr, const int32_t *items, const void *ratings,
+                        const void *X, const void *Y, const void *Mmat, void *out, void *pred_out,
+                        double *sse_out, void *workspace, hipStream_t st) {
     const int ld = imc_ld(q);
-    const ImcWorkspace ws = imc_layout(sizeof(T), n_users, p, q);
+    const ImcWorkspace ws = imc_layout(sizeof(T), n_users, n_samples, p, q);
     char *base = static_cast<char *>(workspace);
     T *Atab = reinterpret_cast<T *>(base + ws.a_off);
     T *Wtab = reinterpret_cast<T *>(base + ws.w_off);
     T *part = reinterpret_cast<T *>(base + ws.part_off);
     double *sse_part = reinterpret_cast<double *>(base + ws.sse_off);
+    T *border = reinterpret_cast<T *>(base + ws.border_off);
+    int64_t *border_user = reinterpret_cast<int64_t *>(base + ws.border_user_off);
 
     // A = X M with the padded row stride; M has q real columns, the pad columns come out zero
     const int64_t tiles_a = ((n_users + 15) / 16) * (ld / 16);
@@ -228,21 +291,29 @@ static int run_imc_eval(int mode, int64_t n_users, int p, int q, const int64_t *
     ALSMI_HIP_CHECK(hipGetLastError());
 
     // d_e, squared error, W = (weights) x Y in one pass over the stored entries
-    int64_t want = (n_users + 3) / 4;
-    const int grid = (int)(want < 1 ? 1 : (want < IMC_SSE_BLOCKS ? want : IMC_SSE_BLOCKS));
-    switch (ld / 16) {
-        case 1: launch_rows<T, 1>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
-        case 2: launch_rows<T, 2>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
-        case 4: launch_rows<T, 4>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
-        case 8: launch_rows<T, 8>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
-        case 16: launch_rows<T, 16>(grid, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out, sse_part, st); break;
-        default:
-            set_error("alsmi_imc_eval: unsupported padded width %d", ld);
-            return ALSMI_EINVAL;
+    ALSMI_HIP_CHECK(hipMemsetAsync(Wtab, 0, (size_t)n_users * ld * sizeof(T), st));
+    const int64_t nc = n_samples > 0 ? ws.n_chunks : 0;
+    if (nc > 0) {
+        switch (ld / 16) {
+#define ALSMI_ROWS(NV)                                                                          \
+    case NV:                                                                                    \
+        launch_rows<T, NV>(nc, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out,  \
+                           border, border_user, sse_part, st);                                  \
+        break;
+            ALSMI_ROWS(1) ALSMI_ROWS(2) ALSMI_ROWS(4) ALSMI_ROWS(8) ALSMI_ROWS(16)
+#undef ALSMI_ROWS
+            default:
+                set_error("alsmi_imc_eval: unsupported padded width %d", ld);
+                return ALSMI_EINVAL;
+        }
+        ALSMI_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL((imc_borders_kernel<T>), dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, st,
+                           nc, ld, border, border_user, Wtab);
+        ALSMI_HIP_CHECK(hipGetLastError());
     }
-    ALSMI_HIP_CHECK(hipGetLastError());
     if (sse_out) {
-        hipLaunchKernelGGL(imc_sum_sse_kernel, dim3(1), dim3(256), 0, st, sse_part, grid, sse_out);
+        hipLaunchKernelGGL(imc_sum_sse_kernel, dim3(1), dim3(256), 0, st, sse_part, (int)nc,
+                           sse_out);
         ALSMI_HIP_CHECK(hipGetLastError());
     }
 
@@ -275,23 +346,53 @@ int alsmi_imc_padded_width(int q) {
     return alsmi::imc_ld(q);
 }
 
-size_t alsmi_imc_workspace_bytes(int dtype, int64_t n_users, int p, int q) {
-    if ((dtype != ALSMI_F32 && dtype != ALSMI_F64) || n_users < 0 || p < 1 || q < 1 ||
-        q > alsmi::IMC_MAX_Q)
+size_t alsmi_imc_workspace_bytes(int dtype, int64_t n_users, int64_t n_samples, int p, int q) {
+    if ((dtype != ALSMI_F32 && dtype != ALSMI_F64) || n_users < 0 || n_samples < 0 || p < 1 ||
+        q < 1 || q > alsmi::IMC_MAX_Q)
         return 0;
-    return alsmi::imc_layout(dtype == ALSMI_F32 ? 4 : 8, n_users, p, q).total;
+    return alsmi::imc_layout(dtype == ALSMI_F32 ? 4 : 8, n_users, n_samples, p, q).total;
 }
 
-int alsmi_imc_eval(int dtype, int mode, int64_t n_users, int p, int q, const int64_t *indptr,
-                   const int32_t *items, const void *ratings, const void *X, const void *Y,
-                   const void *M, void *out, void *pred_out, double *sse_out, void *workspace,
-                   void *stream) {
+int alsmi_imc_project(int dtype, int64_t n_rows, int p, int q, const void *X, const void *M,
+                      void *table_out, void *stream) {
+    using namespace alsmi;
+    ALSMI_REQUIRE(dtype == ALSMI_F32 || dtype == ALSMI_F64, "alsmi_imc_project: bad dtype %d",
+                  dtype);
+    ALSMI_REQUIRE(p >= 1 && q >= 1 && q <= IMC_MAX_Q,
+                  "alsmi_imc_project: need p >= 1 and 1 <= q <= %d (got p=%d q=%d)", IMC_MAX_Q, p, q);
+    ALSMI_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, "alsmi_imc_project: bad row count");
+    if (n_rows == 0) return ALSMI_OK;
+    ALSMI_REQUIRE(X && M && table_out, "alsmi_imc_project: null pointer");
+    const int ld = imc_ld(q);
+    const int64_t tiles = ((n_rows + 15) / 16) * (ld / 16);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ALSMI_F32)
+        hipLaunchKernelGGL((gemm16_kernel<float, false>), dim3((unsigned)((tiles + 3) / 4), 1, 1),
+                           dim3(256), 0, st, (int)n_rows, ld, q, (int64_t)p,
+                           static_cast<const float *>(X), (int64_t)p,
+                           static_cast<const float *>(M), (int64_t)q,
+                           static_cast<float *>(table_out), (int64_t)ld, (int64_t)0);
+    else
+        hipLaunchKernelGGL((gemm16_kernel<double, false>), dim3((unsigned)((tiles + 3) / 4), 1, 1),
+                           dim3(256), 0, st, (int)n_rows, ld, q, (int64_t)p,
+                           static_cast<const double *>(X), (int64_t)p,
+                           static_cast<const double *>(M), (int64_t)q,
+                           static_cast<double *>(table_out), (int64_t)ld, (int64_t)0);
+    ALSMI_HIP_CHECK(hipGetLastError());
+    return ALSMI_OK;
+}
+
+int alsmi_imc_eval(int dtype, int mode, int64_t n_users, int64_t n_samples, int p, int q,
+                   const int64_t *indptr, const int32_t *items, const void *ratings, const void *X,
+                   const void *Y, const void *M, void *out, void *pred_out, double *sse_out,
+                   void *workspace, void *stream) {
     using namespace alsmi;
     ALSMI_REQUIRE(dtype == ALSMI_F32 || dtype == ALSMI_F64, "alsmi_imc_eval: bad dtype %d", dtype);
     ALSMI_REQUIRE(mode == 0 || mode == 1, "alsmi_imc_eval: mode must be 0 or 1, got %d", mode);
     ALSMI_REQUIRE(p >= 1 && q >= 1 && q <= IMC_MAX_Q,
                   "alsmi_imc_eval: need p >= 1 and 1 <= q <= %d (got p=%d q=%d)", IMC_MAX_Q, p, q);
     ALSMI_REQUIRE(n_users >= 0 && n_users < INT32_MAX, "alsmi_imc_eval: bad user count");
+    ALSMI_REQUIRE(n_samples >= 0, "alsmi_imc_eval: bad sample count");
     ALSMI_REQUIRE(mode == 0 || !sse_out, "alsmi_imc_eval: sse_out only exists in mode 0");
     if (n_users == 0) {
         ALSMI_REQUIRE(!out && !sse_out && !pred_out, "alsmi_imc_eval: no users, nothing to write");
@@ -301,10 +402,10 @@ int alsmi_imc_eval(int dtype, int mode, int64_t n_users, int p, int q, const int
     ALSMI_REQUIRE(mode == 1 || ratings, "alsmi_imc_eval: mode 0 needs ratings");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == ALSMI_F32)
-        return run_imc_eval<float>(mode, n_users, p, q, indptr, items, ratings, X, Y, M, out,
-                                   pred_out, sse_out, workspace, st);
-    return run_imc_eval<double>(mode, n_users, p, q, indptr, items, ratings, X, Y, M, out,
-                                pred_out, sse_out, workspace, st);
+        return run_imc_eval<float>(mode, n_users, n_samples, p, q, indptr, items, ratings, X, Y, M,
+                                   out, pred_out, sse_out, workspace, st);
+    return run_imc_eval<double>(mode, n_users, n_samples, p, q, indptr, items, ratings, X, Y, M,
+                                out, pred_out, sse_out, workspace, st);
 }
 
 }  // extern "C"

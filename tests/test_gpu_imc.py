@@ -313,6 +313,21 @@ def test_low_rank_imc_matches_restatement(gpu):
     Zs = rng.standard_normal((p, r)).dot(rng.standard_normal((r, q)))
     vals = io.preds_indexed(Zs, X, Y, users, items) + 0.01 * rng.standard_normal(ns)
     R = sps.csr_matrix((vals, (users, items)), shape=(n, m))
+    # the r-wide evaluation (two passes against projected tables) against the restatement,
+    # whole and as the sum of three user-range shards, in both arithmetic types
+    from alsmi.imc import ImcProblem
+    Ut, Vt = rng.standard_normal((p, r)), rng.standard_normal((q, r))
+    f_want, gu_want, gv_want = io.low_rank_cost_grad(Ut, Vt, X, Y, users, items, vals, 0.0)
+    for dtype, tol in (('float64', 1e-11), ('float32', 1e-4)):
+        sse, gu, gv = ImcProblem(X, Y, users, items, vals, dtype=dtype).low_rank_eval(Ut, Vt)
+        np.testing.assert_allclose(0.5 * sse, f_want, rtol=tol)
+        assert np.abs(gu - gu_want).max() <= tol * np.abs(gu_want).max()
+        assert np.abs(gv - gv_want).max() <= tol * np.abs(gv_want).max()
+    parts = [ImcProblem(X, Y, users, items, vals, shard=(i, 3)).low_rank_eval(Ut, Vt)
+             for i in range(3)]
+    np.testing.assert_allclose(sum(t[0] for t in parts) * 0.5, f_want, rtol=1e-11)
+    np.testing.assert_allclose(sum(t[1] for t in parts), gu_want, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(sum(t[2] for t in parts), gv_want, rtol=1e-9, atol=1e-9)
     est = IMC(n_components=r, alpha=0.01, low_rank=True)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')

@@ -26,6 +26,9 @@ def main():
     ap.add_argument('--small', action='store_true')
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--cpu-frac', type=float, default=0.02)
+    ap.add_argument('--dtype', default='float64', choices=['float32', 'float64'])
+    ap.add_argument('--low-rank', type=int, default=0,
+                    help='also time the rank-constrained evaluation (Z = U V^T) of this rank')
     args = ap.parse_args()
     from alsmi import _lib, synth
     from alsmi import device as dev
@@ -36,20 +39,23 @@ def main():
     indptr, items, vals = prob['csr']
     g = torch.Generator(device=device)
     g.manual_seed(3)
-    X = torch.randn((n, p), generator=g, device=device, dtype=torch.float64) / np.sqrt(p)
+    td = torch.float64 if args.dtype == 'float64' else torch.float32
+    code = _lib.F64 if args.dtype == 'float64' else _lib.F32
+    X = (torch.randn((n, p), generator=g, device=device, dtype=torch.float64) / np.sqrt(p)).to(td)
     ld = _lib.load().alsmi_imc_padded_width(q)
-    Y = torch.zeros((m, ld), device=device, dtype=torch.float64)
-    Y[:, :q] = torch.randn((m, q), generator=g, device=device, dtype=torch.float64) / np.sqrt(q)
-    Z = torch.randn((p, q), generator=g, device=device, dtype=torch.float64) * 0.1
-    ratings = vals.to(torch.float64)
-    out = torch.empty((p, q), device=device, dtype=torch.float64)
+    Y = torch.zeros((m, ld), device=device, dtype=td)
+    Y[:, :q] = (torch.randn((m, q), generator=g, device=device, dtype=torch.float64)
+                / np.sqrt(q)).to(td)
+    Z = (torch.randn((p, q), generator=g, device=device, dtype=torch.float64) * 0.1).to(td)
+    ratings = vals.to(td)
+    out = torch.empty((p, q), device=device, dtype=td)
     sse = torch.zeros(1, device=device, dtype=torch.float64)
-    nbytes = int(_lib.load().alsmi_imc_workspace_bytes(_lib.F64, n, p, q))
+    nbytes = int(_lib.load().alsmi_imc_workspace_bytes(code, n, nnz, p, q))
     ws = torch.empty(nbytes // 8 + 1, device=device, dtype=torch.float64)
 
     def evaluate(mode):
         _lib.check(_lib.load().alsmi_imc_eval(
-            _lib.F64, mode, n, p, q, dev._ptr(indptr), dev._ptr(items), dev._ptr(ratings),
+            code, mode, n, nnz, p, q, dev._ptr(indptr), dev._ptr(items), dev._ptr(ratings),
             dev._ptr(X), dev._ptr(Y), dev._ptr(Z), dev._ptr(out), None,
             dev._ptr(sse) if mode == 0 else None, dev._ptr(ws), dev._stream()), 'alsmi_imc_eval')
 
@@ -69,13 +75,13 @@ def main():
         t_hess += ev[1].elapsed_time(ev[2]) * 1e-3
     t_grad /= args.steps
     t_hess /= args.steps
-    s = 8
+    s = 8 if args.dtype == 'float64' else 4
     algo = nnz * (ld * s + 4 + s) + 2 * n * ld * s   # per evaluation (SDDMM+SpMM pass)
     flops = 4.0 * n * p * q + 4.0 * nnz * q           # two GEMMs + dot and axpy per entry
     line = {
         'metric': 'IMC evaluations/sec (cost+gradient, Hessian-vector), config 3 shape',
-        'config': {'workload': 'IMC n=%d m=%d nnz=%d p=%d q=%d fp64' % (n, m, nnz, p, q)},
-        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'IMC n=%d m=%d nnz=%d p=%d q=%d %s' % (n, m, nnz, p, q, args.dtype)},
+        'dtype': 'f64' if args.dtype == 'float64' else 'f32', 'data': 'synthetic',
         'cost_grad': {'ms': t_grad * 1e3, 'evals_per_sec': 1 / t_grad,
                       'nnz_per_sec': nnz / t_grad, 'GBps': algo / t_grad / 1e9,
                       'frac_of_8TBps': algo / t_grad / 8e12, 'TFLOPs': flops / t_grad / 1e12},
@@ -83,6 +89,27 @@ def main():
                   'frac_of_8TBps': algo / t_hess / 8e12},
         'algorithmic_bytes_per_eval': algo,
     }
+    if args.low_rank:
+        # cost + both gradients of the rank-constrained form: two passes over the samples that
+        # are `low_rank` wide (user-major against Y V, item-major against X U), host
+        # round trip of the p x r and q x r results included
+        from alsmi.imc import ImcProblem
+        r = args.low_rank
+        prob2 = ImcProblem.from_device_csr(indptr, items, ratings, X, Y[:, :q], dtype=args.dtype)
+        rs = np.random.RandomState(0)
+        U0, V0 = rs.randn(p, r) * 0.1, rs.randn(q, r) * 0.1
+        prob2.low_rank_eval(U0, V0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            prob2.low_rank_eval(U0, V0)
+        dt = (time.perf_counter() - t0) / args.steps
+        ldr = _lib.load().alsmi_imc_padded_width(r)
+        algo_lr = 2 * nnz * (ldr * s + 4 + s) + 2 * (n + m) * ldr * s
+        line['low_rank'] = {'rank': r, 'ms': dt * 1e3, 'evals_per_sec': 1 / dt,
+                            'nnz_per_sec': nnz / dt, 'algorithmic_bytes_per_eval': algo_lr,
+                            'GBps': algo_lr / dt / 1e9, 'frac_of_8TBps': algo_lr / dt / 8e12,
+                            'what': 'cost + dU + dV of Z = U V^T'}
     if args.cpu_frac > 0:
         from oracle import c_oracle as co
         rows = max(1, int(n * args.cpu_frac))
@@ -90,9 +117,9 @@ def main():
         cnt = int(ip[-1])
         threads = int(os.environ.get('OMP_NUM_THREADS', '0')) or min(16, os.cpu_count() or 1)
         t0 = time.perf_counter()
-        co.imc_eval(0, ip, items[:cnt].cpu().numpy(), ratings[:cnt].cpu().numpy(),
-                    X[:rows].cpu().numpy(), Y[:, :q].cpu().numpy(), Z.cpu().numpy(),
-                    threads=threads)
+        co.imc_eval(0, ip, items[:cnt].cpu().numpy(), ratings[:cnt].double().cpu().numpy(),
+                    X[:rows].double().cpu().numpy(), Y[:, :q].double().cpu().numpy(),
+                    Z.double().cpu().numpy(), threads=threads)
         dt = (time.perf_counter() - t0) * nnz / max(cnt, 1)
         line['cpu_baseline'] = {'value': 1 / dt, 'unit': 'cost+gradient evaluations/s',
                                 'cores': threads, 'kind': 'port',
