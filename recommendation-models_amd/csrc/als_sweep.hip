@@ -160,7 +160,10 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E
                                            int lane) {
     constexpr int KP = NV * 16;
     // registers: 8 steps in flight cost 8*NV operand registers per lane
-    constexpr int DEEP = (NV * (int)sizeof(T) <= 16) ? 8 : 4;
+#ifndef ALSMI_F64_R128_DEEP
+#define ALSMI_F64_R128_DEEP 4
+#endif
+    constexpr int DEEP = (NV * (int)sizeof(T) <= 16) ? 8 : (NV * (int)sizeof(T) == 64 ? ALSMI_F64_R128_DEEP : 4);
     const int g = lane >> 4, q = lane & 15;
     const T *srcq = src + q * NV;
     int idx_n = 0;
@@ -1073,6 +1076,178 @@ __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int ra
     return !__any(bad != 0 || !(chk < INFINITY));
 }
 
+// ---- fp64 block solver (padded rank 128) --------------------------------------------------------
+// The same block LDL^T as block_solve above, on the fp64 accumulator tiles (lane (g,q), register
+// r = M[g + 4r][q]).  Two differences: an elimination step is four fused multiply-adds per tile
+// with the multipliers and the pivot row fetched by ds_bpermute (there is no fp64 counterpart of
+// the 4x4x1 rank-one instruction), and the trailing update S_IJ -= Z_I^T D^-1 Z_J runs on
+// v_mfma_f64_16x16x4, which — fed two tiles in that layout as both operands, register s at
+// step s — again yields X^T Y.  It replaces an in-LDS Cholesky that kept the whole 128 x 128
+// matrix in LDS (one wave per CU, about a millisecond per row).
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double shfl_d(double v, int src_lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(4 * src_lane, (int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_ds_bpermute(4 * src_lane, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return v + __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double row_allreduce_d(double v) {
+    v = dpp_add_d<0xB1>(v);
+    v = dpp_add_d<0x4E>(v);
+    v = dpp_add_d<0x141>(v);
+    v = dpp_add_d<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double col_allreduce_d(double v) {
+    v += shfl_d(v, (int)(__lane_id() ^ 16));
+    v += shfl_d(v, (int)(__lane_id() ^ 32));
+    return v;
+}
+__device__ __forceinline__ d4 mfma_xty_d(d4 x, d4 y, d4 c) {
+    // (scheduling fences: without them the scaled operands of all the tile updates of a block
+    // are formed up front, which costs more registers than there are)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[s], y[s], c, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    return c;
+}
+
+template <int NV, int K>
+struct PivotBlockD {
+    static __device__ __forceinline__ void run(Gram<double, NV> &G, int lane, double (&y)[NV],
+                                               int &bad, double *stash) {
+        const int g = lane >> 4, q = lane & 15;
+        const bool last_col = q == 15;
+        // R starts as the identity; its last column, which no row operation changes, carries the
+        // block's right-hand side (see PivotBlock)
+        d4 rt, dv = {1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double yrow = shfl_d(y[K], g + 4 * r);  // column -> row layout
+            rt[r] = last_col ? yrow : ((g + 4 * r == q) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int gp = p & 3, rp = p >> 2;  // row p: lane group gp, register rp
+            d4 &a = G.acc[tri_index(K, K, NV)];
+            const double d = read_lane(a[rp], 16 * gp + p);
+            const double inv = 1.0 / d;
+            double m[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // rows at or above the pivot (compile-time known for most r) keep a zero
+                if (4 * r + 3 <= p) {
+                    m[r] = 0.0;
+                } else {
+                    const double colv = shfl_d(a[r], 16 * g + p);  // A[g + 4r][p]
+                    m[r] = (g + 4 * r > p) ? -colv * inv : 0.0;
+                }
+            }
+            double rows[NV + 1];
+#pragma unroll
+            for (int j = K; j < NV; ++j) rows[j] = shfl_d(G.acc[tri_index(K, j, NV)][rp], 16 * gp + q);
+            rows[NV] = shfl_d(rt[rp], 16 * gp + q);
+#pragma unroll
+            for (int j = K; j < NV; ++j) {
+                d4 &t = G.acc[tri_index(K, j, NV)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + 3 > p) t[r] = fma(m[r], rows[j], t[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + 3 > p) rt[r] = fma(m[r], rows[NV], rt[r]);
+            dv[rp] = (g == gp) ? inv : dv[rp];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bad |= (dv[r] > 0.0 && dv[r] < (double)INFINITY) ? 0 : 1;
+        d4 dz, zr, rs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            zr[r] = shfl_d(rt[r], 16 * g + 15);  // z from lane 15 of each lane group
+            dz[r] = dv[r] * zr[r];
+            const double rtrue = last_col ? ((g + 4 * r == 15) ? 1.0 : 0.0) : rt[r];
+            rs[r] = dv[r] * rtrue;
+        }
+#pragma unroll
+        for (int i = K + 1; i < NV; ++i) {
+            const d4 zi = G.acc[tri_index(K, i, NV)];
+#pragma unroll
+            for (int j = i; j < NV; ++j)
+                G.acc[tri_index(i, j, NV)] = mfma_xty_d(zi, -dv * G.acc[tri_index(K, j, NV)],
+                                                        G.acc[tri_index(i, j, NV)]);
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
+            y[i] -= col_allreduce_d(part);
+        }
+        // the block's back-substitution data waits in LDS
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            stash[((K * 8) + r) * WAVE + lane] = rs[r];
+            stash[((K * 8) + 4 + r) * WAVE + lane] = zr[r];
+        }
+        PivotBlockD<NV, K + 1>::run(G, lane, y, bad, stash);
+    }
+};
+template <int NV>
+struct PivotBlockD<NV, NV> {
+    static __device__ __forceinline__ void run(Gram<double, NV> &, int, double (&)[NV], int &,
+                                               double *) {}
+};
+
+template <int NV, int K>
+struct BackBlockD {
+    static __device__ __forceinline__ void run(const Gram<double, NV> &G, double (&xc)[NV],
+                                               double &chk, const double *stash, int lane) {
+        d4 rhs, rsk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rsk[r] = stash[((K * 8) + r) * WAVE + lane];
+            rhs[r] = stash[((K * 8) + 4 + r) * WAVE + lane];
+        }
+        if constexpr (K < NV - 1) {
+            d4 w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = K + 1; j < NV; ++j) w += G.acc[tri_index(K, j, NV)] * xc[j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rhs[r] -= row_allreduce_d(w[r]);
+        }
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += rsk[r] * rhs[r];
+        xc[K] = col_allreduce_d(part);
+        chk += fabs(xc[K]);
+        if constexpr (K > 0) BackBlockD<NV, K - 1>::run(G, xc, chk, stash, lane);
+    }
+};
+
+// Solves the NV*16 system held in G (ridge not yet added); xc[k] of lane (.,q) is the solution
+// component of dimension q*NV + k.  False when a pivot is not positive or the result not finite.
+template <int NV>
+__device__ __forceinline__ bool block_solve_d(Gram<double, NV> &G, int lane, int rank, double ridge,
+                                              double (&xc)[NV], double *stash) {
+    asm volatile("" : "+v"(lane));
+    add_ridge<double, NV>(G, lane, rank, ridge);
+    double y[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) y[e] = col_allreduce_d(G.b[e]);
+    int bad = 0;
+    PivotBlockD<NV, 0>::run(G, lane, y, bad, stash);
+    double chk = 0.0;
+    BackBlockD<NV, NV - 1>::run(G, xc, chk, stash, lane);
+    return !__any(bad != 0 || !(chk < (double)INFINITY));
+}
+
 // Generic in-LDS Cholesky + solve for any KP (two rows per lane at KP = 128).  Works on the
 // upper triangle stored row-major so that every vector access is contiguous over lanes.
 template <typename T, int KP>
@@ -1167,17 +1342,18 @@ constexpr int DUAL_MAX_DEG = 64;
 // <= 64, no dump), the whole matrix otherwise.
 template <typename T, int KP, bool DUMP>
 struct WaveLds {
-    static constexpr bool FAST = !DUMP && (KP <= 64 || (sizeof(T) == 4 && KP <= 128));
-    // work area: fp32 fast path = the row's current vector (error variant) only; fp64 fast
-    // path = the transposition stage; otherwise the whole matrix
-    static constexpr int WORK = FAST ? (sizeof(T) == 4 ? KP : Stage<T, KP < 64 ? KP : 64>::ELEMS)
+    static constexpr bool FAST = !DUMP && KP <= 128;
+    // work area: block-solver paths (fp32; fp64 at padded rank 128) = the row's current vector
+    // (error variant) only; fp64 Gauss-Jordan path = the transposition stage; otherwise (the
+    // dump) the whole matrix
+    static constexpr bool BLOCK = sizeof(T) == 4 || KP == 128;
+    static constexpr int WORK = FAST ? (BLOCK ? KP : Stage<T, KP < 64 ? KP : 64>::ELEMS)
                                      : Slab<T, KP>::ELEMS;
     // + 64 doubles behind the work area: the lanes' squared-error partial sums
     static constexpr int ERR_AT = (WORK + 1) / 2 * 2;
-    // + (fp32, padded rank 128) the back-substitution data of the eight pivot blocks
+    // + (padded rank 128) the back-substitution data of the eight pivot blocks
     static constexpr int STASH_AT = ERR_AT + 512 / (int)sizeof(T);
-    static constexpr int ELEMS =
-        STASH_AT + ((sizeof(T) == 4 && KP == 128 && !DUMP) ? 8 * 8 * WAVE : 0);
+    static constexpr int ELEMS = STASH_AT + ((KP == 128 && !DUMP) ? 8 * 8 * WAVE : 0);
     static constexpr size_t BYTES = (size_t)ELEMS * sizeof(T);
 };
 
@@ -1284,6 +1460,16 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
                     else v[k] = ok ? xs[k] : 0.0f;
                 }
                 *reinterpret_cast<vec_t *>(out + lane * NV) = v;
+            }
+            continue;
+        } else if constexpr (FAST && KP == 128) {
+            double xs[NV];
+            const bool ok = block_solve_d<NV>(G, lane, p.rank, ridge, xs,
+                                              reinterpret_cast<double *>(Asm) +
+                                                  WaveLds<T, KP, DUMP>::STASH_AT);
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) out[lane * NV + k] = ok ? xs[k] : 0.0;
             }
             continue;
         } else if constexpr (FAST) {
