@@ -457,6 +457,105 @@ __device__ __forceinline__ void gram_block_f16(Gram<float, NV> &G, ErrAcc<float,
         }
 }
 
+// The same block in two halves, for the software-pipelined loop of padded rank 128 (two waves
+// per SIMD): gram_fetch issues the block's loads and, once they have arrived, turns them into
+// the operand registers; gram_mma issues the block's matrix instructions.  The loop runs the
+// matrix instructions of block n between the loads of block n+1 and their first use, so that a
+// wave's memory latency and its matrix work overlap (the other wave of the SIMD is in the same
+// loop, or in its solve).
+template <int NV, int J>
+__device__ __forceinline__ void gram_mma(Gram<float, NV> &G,
+                                         const typename F16Op<J>::vec_t (&H)[NV],
+                                         const typename F16Op<J>::vec_t (&L)[NV]) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int f = e; f < NV; ++f) {
+            Mfma<float>::acc_t c = G.acc[tri_index(e, f, NV)];
+            c = F16Op<J>::mma(H[e], L[f], c);
+            c = F16Op<J>::mma(L[e], H[f], c);
+            c = F16Op<J>::mma(H[e], H[f], c);
+            G.acc[tri_index(e, f, NV)] = c;
+        }
+}
+
+template <int NV, int J, bool WIDE>
+__device__ __forceinline__ void gram_issue(float (&v)[J][NV], float (&r)[J],
+                                           const float *__restrict__ src, unsigned qoff, int idx,
+                                           float rv, int off, int g) {
+    constexpr int KP = NV * 16;
+    const int lane_jg = 4 * J * g;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int at = lane_jg + 4 * (off + j);
+        const unsigned id = (unsigned)__builtin_amdgcn_ds_bpermute(at, idx);
+        r[j] = bperm(at, rv);
+        if constexpr (WIDE)
+            load_vec<float, NV>(v[j], reinterpret_cast<const float *>(
+                                          reinterpret_cast<const char *>(src) +
+                                          ((uint64_t)id * (KP * 4u) + qoff)));
+        else
+            load_vec<float, NV>(v[j], reinterpret_cast<const float *>(
+                                          reinterpret_cast<const char *>(src) +
+                                          (id * (KP * 4u) + qoff)));
+    }
+}
+
+template <int NV, int J>
+__device__ __forceinline__ void gram_convert(Gram<float, NV> &G, float (&v)[J][NV],
+                                             const float (&r)[J], int valid, int g, float scale,
+                                             typename F16Op<J>::vec_t (&H)[NV],
+                                             typename F16Op<J>::vec_t (&L)[NV]) {
+    if (valid < 4 * J) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const bool ok = J * g + j < valid;
+#pragma unroll
+            for (int e = 0; e < NV; ++e) v[j][e] = ok ? v[j][e] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) G.b[e] += r[j] * v[j][e];
+    }
+#pragma unroll
+    for (int i = 0; i < J / 2; ++i) {
+        float xs[2][NV], hf[2][NV];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < NV; e += 2) {
+                const f32x2 x = f32x2{v[2 * i + jj][e], v[2 * i + jj][e + 1]} * scale;
+                xs[jj][e] = x[0];
+                xs[jj][e + 1] = x[1];
+            }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const f16x2 h = __builtin_convertvector(f32x2{xs[0][e], xs[1][e]}, f16x2);
+            H[e][2 * i] = h[0];
+            H[e][2 * i + 1] = h[1];
+            hf[0][e] = (float)h[0];
+            hf[1][e] = (float)h[1];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < NV; e += 2) {
+                const f32x2 rest =
+                    f32x2{xs[jj][e], xs[jj][e + 1]} - f32x2{hf[jj][e], hf[jj][e + 1]};
+                xs[jj][e] = rest[0];  // exact
+                xs[jj][e + 1] = rest[1];
+            }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const f16x2 l = __builtin_convertvector(f32x2{xs[0][e], xs[1][e]}, f16x2);
+            L[e][2 * i] = l[0];
+            L[e][2 * i + 1] = l[1];
+        }
+    }
+}
+
 // Waves per SIMD the fp32 rank-64 kernels are compiled for (register budget 512 / waves).
 #ifndef SOLVE_MIN_WAVES
 #define SOLVE_MIN_WAVES 3
@@ -497,12 +596,16 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
     auto block = [&](auto full, int idx, float rv, int off, int valid) {
         constexpr bool FULL = decltype(full)::value;
         if constexpr (is_f16x2(MODE))
-            gram_block_f16<NV, J, FULL ? 1 : 0, MODE == GRAM_F16X2_WIDE, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv,
-                                                     off, valid, g, scale);
+            gram_block_f16<NV, J, FULL ? 1 : 0, MODE == GRAM_F16X2_WIDE, ERR>(
+                G, E, src, (unsigned)(q * NV * 4), idx, rv, off, valid, g, scale);
         else
             gram_block32_split<NV, FULL, ERR>(G, E, srcq, idx, rv, off, valid, g);
     };
     constexpr int BLK = is_f16x2(MODE) ? 4 * J : 32;  // neighbours per block
+    constexpr bool PIPE = NV == 8 && is_f16x2(MODE);
+    // pipelined loop: the operands of the block whose matrix instructions are still to be issued
+    typename F16Op<J>::vec_t H[NV], L[NV];
+    bool pending = false;
     for (int64_t base = beg; base < end; base += WAVE) {
         const int64_t left = end - base;
         const int cnt = left < WAVE ? (int)left : WAVE;
@@ -515,11 +618,18 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
             idx_n = indices[base + WAVE + lane];
             rv_n = vals[base + WAVE + lane];
         }
-        if constexpr (J == 4 && is_f16x2(MODE)) {
+        if constexpr (PIPE) {
 #pragma unroll 1
-            for (int off = 0; off < cnt; off += BLK)
-                gram_block_f16<NV, J, 2, MODE == GRAM_F16X2_WIDE, ERR>(G, E, src, (unsigned)(q * NV * 4), idx, rv, off,
-                                              cnt - off, g, scale);
+            for (int off = 0; off < cnt; off += BLK) {
+                float v[J][NV], r[J];
+                gram_issue<NV, J, MODE == GRAM_F16X2_WIDE>(v, r, src, (unsigned)(q * NV * 4), idx,
+                                                           rv, off, g);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pending) gram_mma<NV, J>(G, H, L);  // the previous block, under the loads
+                __builtin_amdgcn_sched_barrier(0);
+                gram_convert<NV, J>(G, v, r, cnt - off, g, scale, H, L);
+                pending = true;
+            }
         } else {
 #pragma unroll
             for (int off = 0; off < WAVE; off += BLK) {
@@ -529,6 +639,9 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
                     block(std::false_type{}, idx, rv, off, cnt - off);
             }
         }
+    }
+    if constexpr (PIPE) {
+        if (pending) gram_mma<NV, J>(G, H, L);
     }
 }
 
