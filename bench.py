@@ -377,7 +377,7 @@ def main():
                         'traffic is far below them the gathered table is cache resident and '
                         'the side is bound by instruction issue (see the per-side entries)',
                 'kernel': 'half-sweep launch = max_abs + gram_chunks + sum_slabs + solve_rows '
-                          '(+ solve_rows_dual at padded rank 128), mean of user side and item side',
+                          '(+ solve_rows_dual for short rows at padded rank 64 and 128), mean of user side and item side',
                 'bytes_per_launch': (b_user + b_item) / 2.0,
                 'ms_per_launch': (t_user + t_item) / 2.0 * 1e3,
                 'user_side': side_report(t_user, b_user, counters, 'user_side'),

@@ -81,9 +81,15 @@ int alsmi_plan_info(const alsmi_plan *plan, int64_t *n_rows, int64_t *n_heavy_ro
  * ALSMI_F32: the products f f^T are formed on the fp16 matrix cores
  * from values scaled by a power of two taken from the largest |element| of the
  * source table (read once per call); the result has fp32 accuracy for
- * 2^-40 <= max|src| <= 2^40 and a source table of at most 4 GiB, elements below
- * max|src| * 2^-16 lose precision relative to themselves only.  Results are
- * bit-reproducible from run to run. */
+ * 2^-40 <= max|src| <= 2^40, elements below max|src| * 2^-16 lose precision
+ * relative to themselves only.  An fp32 source table above 4 GiB is accepted
+ * at padded rank 128 (64-bit gather addresses are switched in) and rejected
+ * with ALSMI_EINVAL at padded rank <= 64 (more than 16.7 M rows).  At padded
+ * rank 64 / 128 rows of at most 48 / 64 stored entries are solved in the
+ * equivalent n x n form x = F^T (F F^T + alpha n I)^-1 vals; with alpha = 0
+ * such a row gets the minimum-norm least-squares solution where the rank x rank
+ * matrix of the reference is singular.  Results are bit-reproducible from run
+ * to run. */
 int alsmi_half_sweep(alsmi_plan *plan, const int64_t *indptr, const int32_t *indices,
                      const void *vals, const void *src_factors, int64_t n_src,
                      void *dst_factors, double alpha, void *stream);

@@ -148,7 +148,7 @@ class ALS(BaseEstimator):
         def to_rmse(sse, recheck=False):
             """sqrt(sse / nnz).  The fused error is a difference of three sums (sum r^2 -
             2 u.b + u^T G u); in float32 on a near-exact fit they cancel to rounding noise,
-            possibly below zero.  When it falls under 1e-5 of sum r^2 and the factors it
+            possibly below zero.  When it falls under 1e-5 of sum r^2 (or is not finite) and the factors it
             belongs to are still in place (`recheck`), the standalone pass (fp64 accumulation
             of per-entry residuals) replaces it; otherwise it is clamped at zero."""
             nonlocal sum_sq
@@ -158,7 +158,7 @@ class ALS(BaseEstimator):
             if self.dtype == 'float32' or np.dtype(self.dtype) == np.float32:
                 if sum_sq is None:
                     sum_sq = engine.sum_sq_ratings()
-                if value < 1e-5 * sum_sq:
+                if not np.isfinite(value) or value < 1e-5 * sum_sq:
                     if recheck:
                         return engine.train_rmse()
                     value = max(value, 0.0)
