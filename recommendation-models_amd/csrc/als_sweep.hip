@@ -1035,6 +1035,64 @@ __device__ __forceinline__ f4 mfma_xty(f4 x, f4 y, f4 c) {
     return c;
 }
 
+// ---- trailing updates of the block solver on the fp16 matrix cores -----------------------------
+// S_IJ -= Z_I^T D^-1 Z_J is 60 % of the solver's matrix-pipe time on the fp32 instruction (32
+// busy cycles per 16x16x4, and the vector ALU waits meanwhile).  With Zs = D^-1/2 Z it is
+// Zs_I^T Zs_J, the Cholesky form, whose elements are bounded by the square root of the largest
+// diagonal element of the matrix; solve_prescale() brings that into [2^27, 2^28) by a power of
+// two (exact; the right-hand side takes the same factor, the solution none), so |Zs| < 2^14 and
+// the two-way fp16 split h + l of the Gram build applies: hh' + hl' + lh' on three
+// v_mfma_f32_16x16x16_f16 (8 busy cycles each, vector ALU free) instead of four fp32 ones per
+// tile, with an error of 2^-22 of the largest diagonal element per product at worst, the same
+// size as the rounding of the fp32 accumulation of a full row.  A tile in the accumulator layout
+// (lane (g,q) register r = Z[4g+r][q]) IS the f16x4 operand (lane (g,q): k = 4g .. 4g+3 of
+// column q) once converted, on either side, and two of them give X^T Y.
+struct SplitTile {
+    f16x4 h, l;
+};
+__device__ __forceinline__ SplitTile split_tile(f4 z) {
+    SplitTile t;
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        const f32x2 x = {z[r], z[r + 1]};
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 rest = x - __builtin_convertvector(h, f32x2);  // exact
+        const f16x2 l = __builtin_convertvector(rest, f16x2);
+        t.h[r] = h[0];
+        t.h[r + 1] = h[1];
+        t.l[r] = l[0];
+        t.l[r + 1] = l[1];
+    }
+    return t;
+}
+__device__ __forceinline__ f16x4 negate(f16x4 v) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 b = __builtin_bit_cast(u32x2, v);
+    b ^= 0x80008000u;
+    return __builtin_bit_cast(f16x4, b);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+    return fmaxf(v, __builtin_bit_cast(float, t));
+}
+// The power of two that brings the largest diagonal element (of the real unknowns; `dmax` is
+// this lane's share of them) into [2^27, 2^28); 1 when there is no positive finite one.
+__device__ __forceinline__ float prescale_factor(float dmax) {
+    dmax = dpp_max<0xB1>(dmax);
+    dmax = dpp_max<0x4E>(dmax);
+    dmax = dpp_max<0x141>(dmax);
+    dmax = dpp_max<0x140>(dmax);
+    dmax = fmaxf(dmax, __shfl_xor(dmax, 16));
+    dmax = fmaxf(dmax, __shfl_xor(dmax, 32));
+    const unsigned bits = __builtin_bit_cast(unsigned, dmax);
+    const int eb = (int)(bits >> 23) & 0xFF;
+    int field = 127 + 27 + 127 - eb;
+    field = field < 1 ? 1 : (field > 254 ? 254 : field);
+    const bool usable = dmax > 0.0f && eb != 255 && eb != 0;
+    return usable ? __builtin_bit_cast(float, (unsigned)field << 23) : 1.0f;
+}
+
 // Lane constants of the block solver.
 struct SolveLane {
     int lane, g, q, irow, addr_row, addr_col;
@@ -1044,7 +1102,8 @@ struct SolveLane {
 // Forward phase of pivot block K (see above); K is a template parameter so that every tile
 // index is static — a loop over K that the optimiser declines to unroll would turn the
 // accumulators into scratch memory.
-template <int NV, int K>
+// TR16: trailing updates on the fp16 matrix cores (the system has been through the prescale).
+template <int NV, int K, bool TR16>
 struct PivotBlock {
     static __device__ __forceinline__ void run(Gram<float, NV> &G, const SolveLane &L,
                                                float (&y)[NV], f4 (&rs)[NV], f4 (&zr)[NV],
@@ -1094,13 +1153,38 @@ struct PivotBlock {
             const float rtrue = L.last_col ? ((4 * g + r == 15) ? 1.0f : 0.0f) : rt[r];
             rs[K][r] = dv[r] * rtrue;
         }
+        if constexpr (!TR16) {
+#pragma unroll
+            for (int i = K + 1; i < NV; ++i) {
+                const f4 zi = G.acc[tri_index(K, i, NV)];
+#pragma unroll
+                for (int j = i; j < NV; ++j)
+                    G.acc[tri_index(i, j, NV)] = mfma_xty(zi, -dv * G.acc[tri_index(K, j, NV)],
+                                                          G.acc[tri_index(i, j, NV)]);
+            }
+        } else if constexpr (K + 1 < NV) {
+            f4 sd;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sd[r] = __builtin_amdgcn_sqrtf(dv[r]);
+            SplitTile zs[NV];
+#pragma unroll
+            for (int j = K + 1; j < NV; ++j) zs[j] = split_tile(G.acc[tri_index(K, j, NV)] * sd);
+            // product by product over all tiles, so that consecutive matrix instructions do not
+            // wait on each other's accumulator
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = K + 1; i < NV; ++i) {
+                    const f16x4 a = negate(term == 1 ? zs[i].l : zs[i].h);
+#pragma unroll
+                    for (int j = i; j < NV; ++j)
+                        G.acc[tri_index(i, j, NV)] = __builtin_amdgcn_mfma_f32_16x16x16f16(
+                            a, term == 0 ? zs[j].l : zs[j].h, G.acc[tri_index(i, j, NV)], 0, 0, 0);
+                }
+        }
 #pragma unroll
         for (int i = K + 1; i < NV; ++i) {
             const f4 zi = G.acc[tri_index(K, i, NV)];
-#pragma unroll
-            for (int j = i; j < NV; ++j)
-                G.acc[tri_index(i, j, NV)] = mfma_xty(zi, -dv * G.acc[tri_index(K, j, NV)],
-                                                      G.acc[tri_index(i, j, NV)]);
             float part = 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
@@ -1113,11 +1197,11 @@ struct PivotBlock {
                 stash[((K * 8) + 4 + r) * WAVE + L.lane] = zr[K][r];
             }
         }
-        PivotBlock<NV, K + 1>::run(G, L, y, rs, zr, bad, stash);
+        PivotBlock<NV, K + 1, TR16>::run(G, L, y, rs, zr, bad, stash);
     }
 };
-template <int NV>
-struct PivotBlock<NV, NV> {
+template <int NV, bool TR16>
+struct PivotBlock<NV, NV, TR16> {
     static __device__ __forceinline__ void run(Gram<float, NV> &, const SolveLane &, float (&)[NV],
                                                f4 (&)[NV], f4 (&)[NV], int &, float *) {}
 };
@@ -1179,11 +1263,31 @@ __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int ra
     float y[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) y[e] = col_allreduce(G.b[e]);
+    // The neighbour systems of short rows keep the fp32 instruction: their solve is a small part
+    // of their kernels and the split's registers would cost them a wave per SIMD.
+    constexpr bool TR16 = !DUAL && NV > 1;
+    if constexpr (TR16) {
+        // largest diagonal element of the real unknowns -> [2^27, 2^28) (see split_tile above)
+        float dmax = 0.0f;
+#pragma unroll
+        for (int e = 0; e < NV; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool real = DUAL ? (16 * e + L.q < rank) : (L.q * NV + e < rank);
+                const bool diag = 4 * L.g + r == L.q;
+                dmax = fmaxf(dmax, (diag && real) ? G.acc[tri_index(e, e, NV)][r] : 0.0f);
+            }
+        const float tau = prescale_factor(dmax);
+#pragma unroll
+        for (int k = 0; k < Gram<float, NV>::NTRI; ++k) G.acc[k] *= tau;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) y[e] *= tau;
+    }
     // Per pivot block, kept for the back substitution: D^-1 inv(L_kk) (rows scaled) and
     // z_k = inv(L_kk) y_k in the row layout.
     f4 rs[NV], zr[NV];
     int bad = 0;
-    PivotBlock<NV, 0>::run(G, L, y, rs, zr, bad, stash);
+    PivotBlock<NV, 0, TR16>::run(G, L, y, rs, zr, bad, stash);
     float chk = 0.0f;
     BackBlock<NV, NV - 1>::run(G, rs, zr, xc, chk, stash, lane);
     return !__any(bad != 0 || !(chk < INFINITY));
@@ -1630,16 +1734,30 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
 // KP x KP kernel uses.
 // Waves per SIMD the dual kernels are compiled for: all loads of a row are in flight at once,
 // which at 64 neighbours needs the registers of two waves per SIMD.
+#ifndef DUAL_ABLATE
+#define DUAL_ABLATE 0  // timing builds only: 1 no solve, 2 no x = F^T w pass, 4 no error pass
+#endif
+#ifndef DUAL_KEEP_MAX
+#define DUAL_KEEP_MAX 2  // largest ND whose neighbour rows stay in registers for the whole row
+#endif
 #ifndef DUAL64_MIN_WAVES
 #define DUAL64_MIN_WAVES 2
 #endif
 #ifndef DUAL32_MIN_WAVES
 #define DUAL32_MIN_WAVES 4
 #endif
+constexpr int dual_min_waves(int nv, int nd, bool err) {
+    const bool keep = nd <= DUAL_KEEP_MAX;
+    if (nd > 3) return DUAL64_MIN_WAVES;
+    if (nd == 3) return keep && nv == 8 ? 2 : 3;
+    if (nd == 2 && keep && err && nv == 8) return 3;
+    return DUAL32_MIN_WAVES;
+}
 template <int NV, int ND, bool ERR>
-__global__ __launch_bounds__(256, (ND > 3 ? DUAL64_MIN_WAVES : (ND > 2 ? 3 : DUAL32_MIN_WAVES))) void solve_rows_dual_kernel(SolveArgs<float> p) {
+__global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_dual_kernel(SolveArgs<float> p) {
     constexpr int KP = NV * 16;
     constexpr int NC = KP / 32;  // 32-dimension chunks, one matrix instruction deep each
+    constexpr bool KEEP = ND <= DUAL_KEEP_MAX;
     static_assert(KP % 32 == 0 && ND * 16 <= WAVE, "one index block per row");
     const int lane = threadIdx.x & 63;
     const int wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1678,12 +1796,38 @@ __global__ __launch_bounds__(256, (ND > 3 ? DUAL64_MIN_WAVES : (ND > 2 ? 3 : DUA
         float pred[ND];
 #pragma unroll
         for (int a = 0; a < ND; ++a) pred[a] = 0.0f;
+        // KEEP: the neighbours' rows stay in registers from here to the end of the row (32 ND
+        // registers), so the two later passes over them cost no loads; otherwise they are
+        // re-read (cache hits) before each pass.
+        float keep[KEEP ? NC : 1][KEEP ? ND : 1][8];
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+                    load_vec<float, 8>(keep[c][a], srcg + ((int64_t)id[a] * KP + 32 * c));
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            float v[ND][8];
+            float vl[KEEP ? 1 : ND][8];
+            if constexpr (!KEEP) {
 #pragma unroll
-            for (int a = 0; a < ND; ++a)
-                load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
+                for (int a = 0; a < ND; ++a)
+                    load_vec<float, 8>(vl[a], srcg + ((int64_t)id[a] * KP + 32 * c));
+            }
+            auto &v = [&]() -> float(&)[ND][8] {
+                if constexpr (KEEP) return keep[c]; else return vl;
+            }();
+            if constexpr (ERR && KEEP) {
+                // <current vector, neighbour> rides along (the current vector may live in the
+                // table being written: it is read before the row's store)
+                float uc[8];
+                load_vec<float, 8>(uc, p.cur + ((int64_t)row * KP + 32 * c) + 8 * g);
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pred[a] += v[a][j] * uc[j];
+            }
             f16x8 H[ND], L[ND];
 #pragma unroll
             for (int a = 0; a < ND; ++a) {
@@ -1721,22 +1865,52 @@ __global__ __launch_bounds__(256, (ND > 3 ? DUAL64_MIN_WAVES : (ND > 2 ? 3 : DUA
             G.b[a] = g == 0 ? ra * s2 : 0.0f;
         }
         float w[ND];
+#if DUAL_ABLATE & 1
+        const bool ok = true;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            float t = G.b[a];
+#pragma unroll
+            for (int b = a; b < ND; ++b)
+                for (int r = 0; r < 4; ++r) t += G.acc[tri_index(a, b, ND)][r];
+            w[a] = t;
+        }
+#else
         const bool ok = block_solve<ND, true>(G, lane, n, p.alpha * (float)n * s2, w);
+#endif
         // x = F^T w: this lane's neighbours again (a lane past the row's end re-reads the
         // row's first neighbour with a zero weight), 8 dimensions of each chunk; then the sum
         // over the 16 lanes of a lane group, as a reduce-scatter: after the exchanges over
         // lane bits 3 and 2 a lane keeps one chunk, after bits 1 and 0 two dimensions of it.
         float xp[NC][8];
-        // (the optimiser must not keep the first pass's 128 loaded registers alive through the
-        // solve in order to skip these loads)
+        // (without KEEP the optimiser must not keep the first pass's loaded registers alive
+        // through the solve in order to skip these loads)
+        if constexpr (!KEEP) {
 #pragma unroll
-        for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(id[a]));
+            for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(id[a]));
+        }
+#if DUAL_ABLATE & 2
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc += (float)(c + j + 1) * (ok ? w[a] : 0.0f);
+                xp[c][j] = acc;
+            }
+#else
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            float v[ND][8];
+            float vl[KEEP ? 1 : ND][8];
+            if constexpr (!KEEP) {
 #pragma unroll
-            for (int a = 0; a < ND; ++a)
-                load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
+                for (int a = 0; a < ND; ++a)
+                    load_vec<float, 8>(vl[a], srcg + ((int64_t)id[a] * KP + 32 * c));
+            }
+            auto &v = [&]() -> float(&)[ND][8] {
+                if constexpr (KEEP) return keep[c]; else return vl;
+            }();
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float acc = 0.0f;
@@ -1745,6 +1919,7 @@ __global__ __launch_bounds__(256, (ND > 3 ? DUAL64_MIN_WAVES : (ND > 2 ? 3 : DUA
                 xp[c][j] = acc;
             }
         }
+#endif
         static_assert(NC == 4 || NC == 2, "chunks per row");
         const bool b3 = q & 8, b2 = q & 4, b1 = q & 2, b0 = q & 1;
         float s8[8], s4[4], s2[2];
@@ -1793,24 +1968,26 @@ __global__ __launch_bounds__(256, (ND > 3 ? DUAL64_MIN_WAVES : (ND > 2 ? 3 : DUA
             const float give = b0 ? s4[j] : s4[2 + j];
             s2[j] = keep + dpp_get<0xB1>(give);  // quad_perm [1,0,3,2] = lane q ^ 1
         }
-        if constexpr (ERR) {
-            // <current vector, neighbour> per neighbour, in a pass of its own over the rows
-            // (cache hits by now): inside the pass above it costs a wave per SIMD in
-            // registers.  The current vector may live in the table being written: read it
-            // before the store below.
+        if constexpr (ERR && !(DUAL_ABLATE & 4)) {
+            if constexpr (!KEEP) {
+                // <current vector, neighbour> per neighbour, in a pass of its own over the
+                // rows (cache hits by now): inside the first pass it costs a wave per SIMD in
+                // registers.  The current vector may live in the table being written: read
+                // it before the store below.
 #pragma unroll
-            for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(id[a]));
+                for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(id[a]));
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float v[ND][8], uc[8];
-                load_vec<float, 8>(uc, p.cur + ((int64_t)row * KP + 32 * c) + 8 * g);
+                for (int c = 0; c < NC; ++c) {
+                    float v[ND][8], uc[8];
+                    load_vec<float, 8>(uc, p.cur + ((int64_t)row * KP + 32 * c) + 8 * g);
 #pragma unroll
-                for (int a = 0; a < ND; ++a)
-                    load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
+                    for (int a = 0; a < ND; ++a)
+                        load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
 #pragma unroll
-                for (int a = 0; a < ND; ++a)
+                    for (int a = 0; a < ND; ++a)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pred[a] += v[a][j] * uc[j];
+                        for (int j = 0; j < 8; ++j) pred[a] += v[a][j] * uc[j];
+                }
             }
 #pragma unroll
             for (int a = 0; a < ND; ++a) {
