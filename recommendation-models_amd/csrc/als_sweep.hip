@@ -321,6 +321,31 @@ __device__ __forceinline__ float split_scale(unsigned max_bits) {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// Low part of the split of two values x0*s0, x1*s1 whose high parts are the halves of h:
+// fp16(x*s - h) by v_fma_mixlo/mixhi_f16, a fused multiply-add with fp32 and fp16 operands
+// rounded once to fp16: one instruction per element instead of the two of "convert h back,
+// subtract, round".  With s a power of two x*s - h is exactly representable in fp32 and both
+// ways give the same bits (tools/probe/mix_probe.hip).  The compiler selects these instructions
+// only here and there by itself, hence the inline assembly.  The wait states the compiler puts
+// between a vector instruction and a matrix instruction that reads its result do not cover
+// registers written by inline assembly (without them one row in some thousands came out
+// wrong): every caller runs split_fence() between its last split_low and the first matrix
+// instruction that reads the results.
+__device__ __forceinline__ f16x2 split_low(f16x2 h, float x0, float s0, float x1, float s1) {
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    unsigned out;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%5 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(out)
+        : "v"(x0), "v"(s0), "v"(x1), "v"(s1), "v"(hb));
+    return __builtin_bit_cast(f16x2, out);
+}
+__device__ __forceinline__ void split_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // One block of 4*J neighbours (J per lane group): J = 8 feeds v_mfma_f32_16x16x32_f16, J = 4
 // the half-depth v_mfma_f32_16x16x16_f16 (half the operand registers per block; what padded
 // rank 128 needs to run two waves per SIMD beside its 36 accumulator tiles).
@@ -402,7 +427,7 @@ __device__ __forceinline__ void gram_block_f16(Gram<float, NV> &G, ErrAcc<float,
     typename F16Op<J>::vec_t H[NV], L[NV];
 #pragma unroll
     for (int i = 0; i < J / 2; ++i) {
-        float xs[2][NV], hf[2][NV];
+        float xs[2][NV];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             if constexpr (NV >= 2) {
@@ -421,30 +446,12 @@ __device__ __forceinline__ void gram_block_f16(Gram<float, NV> &G, ErrAcc<float,
             const f16x2 h = __builtin_convertvector(f32x2{xs[0][e], xs[1][e]}, f16x2);
             H[e][2 * i] = h[0];
             H[e][2 * i + 1] = h[1];
-            hf[0][e] = (float)h[0];
-            hf[1][e] = (float)h[1];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            if constexpr (NV >= 2) {
-#pragma unroll
-                for (int e = 0; e < NV; e += 2) {
-                    const f32x2 rest =
-                        f32x2{xs[jj][e], xs[jj][e + 1]} - f32x2{hf[jj][e], hf[jj][e + 1]};
-                    xs[jj][e] = rest[0];  // exact
-                    xs[jj][e + 1] = rest[1];
-                }
-            } else {
-                xs[jj][0] -= hf[jj][0];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const f16x2 l = __builtin_convertvector(f32x2{xs[0][e], xs[1][e]}, f16x2);
+            const f16x2 l = split_low(h, v[2 * i][e], scale, v[2 * i + 1][e], scale);
             L[e][2 * i] = l[0];
             L[e][2 * i + 1] = l[1];
         }
     }
+    split_fence();
 #pragma unroll
     for (int e = 0; e < NV; ++e)
 #pragma unroll
@@ -521,7 +528,7 @@ __device__ __forceinline__ void gram_convert(Gram<float, NV> &G, float (&v)[J][N
     }
 #pragma unroll
     for (int i = 0; i < J / 2; ++i) {
-        float xs[2][NV], hf[2][NV];
+        float xs[2][NV];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -535,21 +542,7 @@ __device__ __forceinline__ void gram_convert(Gram<float, NV> &G, float (&v)[J][N
             const f16x2 h = __builtin_convertvector(f32x2{xs[0][e], xs[1][e]}, f16x2);
             H[e][2 * i] = h[0];
             H[e][2 * i + 1] = h[1];
-            hf[0][e] = (float)h[0];
-            hf[1][e] = (float)h[1];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int e = 0; e < NV; e += 2) {
-                const f32x2 rest =
-                    f32x2{xs[jj][e], xs[jj][e + 1]} - f32x2{hf[jj][e], hf[jj][e + 1]};
-                xs[jj][e] = rest[0];  // exact
-                xs[jj][e + 1] = rest[1];
-            }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            const f16x2 l = __builtin_convertvector(f32x2{xs[0][e], xs[1][e]}, f16x2);
+            const f16x2 l = split_low(h, v[2 * i][e], scale, v[2 * i + 1][e], scale);
             L[e][2 * i] = l[0];
             L[e][2 * i + 1] = l[1];
         }
@@ -628,6 +621,7 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
                 if (pending) gram_mma<NV, J>(G, H, L);  // the previous block, under the loads
                 __builtin_amdgcn_sched_barrier(0);
                 gram_convert<NV, J>(G, v, r, cnt - off, g, scale, H, L);
+                split_fence();
                 pending = true;
             }
         } else {
@@ -1050,14 +1044,13 @@ __device__ __forceinline__ f4 mfma_xty(f4 x, f4 y, f4 c) {
 struct SplitTile {
     f16x4 h, l;
 };
-__device__ __forceinline__ SplitTile split_tile(f4 z) {
+__device__ __forceinline__ SplitTile split_tile(f4 z, f4 s) {
     SplitTile t;
 #pragma unroll
     for (int r = 0; r < 4; r += 2) {
-        const f32x2 x = {z[r], z[r + 1]};
+        const f32x2 x = f32x2{z[r], z[r + 1]} * f32x2{s[r], s[r + 1]};
         const f16x2 h = __builtin_convertvector(x, f16x2);
-        const f32x2 rest = x - __builtin_convertvector(h, f32x2);  // exact
-        const f16x2 l = __builtin_convertvector(rest, f16x2);
+        const f16x2 l = split_low(h, z[r], s[r], z[r + 1], s[r + 1]);  // (z s exact in the fma)
         t.h[r] = h[0];
         t.h[r + 1] = h[1];
         t.l[r] = l[0];
@@ -1168,7 +1161,8 @@ struct PivotBlock {
             for (int r = 0; r < 4; ++r) sd[r] = __builtin_amdgcn_sqrtf(dv[r]);
             SplitTile zs[NV];
 #pragma unroll
-            for (int j = K + 1; j < NV; ++j) zs[j] = split_tile(G.acc[tri_index(K, j, NV)] * sd);
+            for (int j = K + 1; j < NV; ++j) zs[j] = split_tile(G.acc[tri_index(K, j, NV)], sd);
+            split_fence();
             // product by product over all tiles, so that consecutive matrix instructions do not
             // wait on each other's accumulator
 #pragma unroll
@@ -1836,17 +1830,18 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
                 const bool maybe_partial = a == ND - 1;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    f32x2 x = f32x2{v[a][j], v[a][j + 1]} * scale;
-                    if (maybe_partial) x = real[a] ? x : f32x2{0.0f, 0.0f};
+                    f32x2 u = f32x2{v[a][j], v[a][j + 1]};
+                    if (maybe_partial) u = real[a] ? u : f32x2{0.0f, 0.0f};
+                    const f32x2 x = u * scale;
                     const f16x2 h = __builtin_convertvector(x, f16x2);
-                    const f32x2 rest = x - __builtin_convertvector(h, f32x2);  // exact
-                    const f16x2 l = __builtin_convertvector(rest, f16x2);
+                    const f16x2 l = split_low(h, u[0], scale, u[1], scale);
                     H[a][j] = h[0];
                     H[a][j + 1] = h[1];
                     L[a][j] = l[0];
                     L[a][j + 1] = l[1];
                 }
             }
+            split_fence();
 #pragma unroll
             for (int a = 0; a < ND; ++a)
 #pragma unroll
