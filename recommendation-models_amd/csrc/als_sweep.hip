@@ -1740,8 +1740,15 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
 #ifndef DUAL32_MIN_WAVES
 #define DUAL32_MIN_WAVES 4
 #endif
+// Do the neighbours' rows of a short row stay in registers for the whole row (32 ND registers at
+// padded rank 128, 16 ND at 64)?  Up to 32 entries always; 33 to 48 entries at padded rank 64,
+// and at 128 in the error variant, which would otherwise read them three times (measured: with
+// two reads only, the wave per SIMD this costs outweighs the second read).
+constexpr bool dual_keep(int nv, int nd, bool err) {
+    return nd <= DUAL_KEEP_MAX || (nd == 3 && (nv == 4 || err));
+}
 constexpr int dual_min_waves(int nv, int nd, bool err) {
-    const bool keep = nd <= DUAL_KEEP_MAX;
+    const bool keep = dual_keep(nv, nd, err);
     if (nd > 3) return DUAL64_MIN_WAVES;
     if (nd == 3) return keep && nv == 8 ? 2 : 3;
     if (nd == 2 && keep && err && nv == 8) return 3;
@@ -1751,7 +1758,7 @@ template <int NV, int ND, bool ERR>
 __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_dual_kernel(SolveArgs<float> p) {
     constexpr int KP = NV * 16;
     constexpr int NC = KP / 32;  // 32-dimension chunks, one matrix instruction deep each
-    constexpr bool KEEP = ND <= DUAL_KEEP_MAX;
+    constexpr bool KEEP = dual_keep(NV, ND, ERR);
     static_assert(KP % 32 == 0 && ND * 16 <= WAVE, "one index block per row");
     const int lane = threadIdx.x & 63;
     const int wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1906,6 +1913,18 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
             auto &v = [&]() -> float(&)[ND][8] {
                 if constexpr (KEEP) return keep[c]; else return vl;
             }();
+            if constexpr (ERR && !KEEP && !(DUAL_ABLATE & 4)) {
+                // <current vector, neighbour> rides along with this pass (in the first one it
+                // would cost a wave per SIMD in registers, beside the accumulator tiles).  The
+                // current vector may live in the table being written: the row's store comes
+                // after this loop.
+                float uc[8];
+                load_vec<float, 8>(uc, p.cur + ((int64_t)row * KP + 32 * c) + 8 * g);
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pred[a] += v[a][j] * uc[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float acc = 0.0f;
@@ -1964,26 +1983,6 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
             s2[j] = keep + dpp_get<0xB1>(give);  // quad_perm [1,0,3,2] = lane q ^ 1
         }
         if constexpr (ERR && !(DUAL_ABLATE & 4)) {
-            if constexpr (!KEEP) {
-                // <current vector, neighbour> per neighbour, in a pass of its own over the
-                // rows (cache hits by now): inside the first pass it costs a wave per SIMD in
-                // registers.  The current vector may live in the table being written: read
-                // it before the store below.
-#pragma unroll
-                for (int a = 0; a < ND; ++a) asm volatile("" : "+v"(id[a]));
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    float v[ND][8], uc[8];
-                    load_vec<float, 8>(uc, p.cur + ((int64_t)row * KP + 32 * c) + 8 * g);
-#pragma unroll
-                    for (int a = 0; a < ND; ++a)
-                        load_vec<float, 8>(v[a], srcg + ((int64_t)id[a] * KP + 32 * c));
-#pragma unroll
-                    for (int a = 0; a < ND; ++a)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) pred[a] += v[a][j] * uc[j];
-                }
-            }
 #pragma unroll
             for (int a = 0; a < ND; ++a) {
                 const float ra = bperm(4 * (16 * a + q), rv);
