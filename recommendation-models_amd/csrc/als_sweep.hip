@@ -474,16 +474,42 @@ template <int NV, int J>
 __device__ __forceinline__ void gram_mma(Gram<float, NV> &G,
                                          const typename F16Op<J>::vec_t (&H)[NV],
                                          const typename F16Op<J>::vec_t (&L)[NV]) {
+    if constexpr (J == 4) {
+        // The half-depth instruction runs at half the rate of the full-depth one (both take 16
+        // cycles).  With a lane's eight contraction slots = its four neighbours twice, one
+        // full-depth instruction takes two products of a tile at once:
+        //   [H_e | L_e]^T [L_f | H_f] = H_e^T L_f + L_e^T H_f,   [H_e | L_e]^T [H_f | 0] = H_e^T H_f,
+        // 32 instead of 48 matrix-pipe cycles per tile and block.  The right-hand operands are
+        // put together per tile column (register moves), so that only one pair is live at a
+        // time.  (The second product as a half-depth instruction behind the first gave garbage
+        // in some tiles: two matrix instructions of different depth back to back on one
+        // accumulator.)
+        const f16x4 zero4 = {0, 0, 0, 0};
 #pragma unroll
-    for (int e = 0; e < NV; ++e)
+        for (int f = 0; f < NV; ++f) {
+            const f16x8 lh = __builtin_shufflevector(L[f], H[f], 0, 1, 2, 3, 4, 5, 6, 7);
+            const f16x8 h0 = __builtin_shufflevector(H[f], zero4, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-        for (int f = e; f < NV; ++f) {
-            Mfma<float>::acc_t c = G.acc[tri_index(e, f, NV)];
-            c = F16Op<J>::mma(H[e], L[f], c);
-            c = F16Op<J>::mma(L[e], H[f], c);
-            c = F16Op<J>::mma(H[e], H[f], c);
-            G.acc[tri_index(e, f, NV)] = c;
+            for (int e = 0; e <= f; ++e) {
+                const f16x8 hl = __builtin_shufflevector(H[e], L[e], 0, 1, 2, 3, 4, 5, 6, 7);
+                Mfma<float>::acc_t c = G.acc[tri_index(e, f, NV)];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hl, lh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hl, h0, c, 0, 0, 0);
+                G.acc[tri_index(e, f, NV)] = c;
+            }
         }
+    } else {
+#pragma unroll
+        for (int e = 0; e < NV; ++e)
+#pragma unroll
+            for (int f = e; f < NV; ++f) {
+                Mfma<float>::acc_t c = G.acc[tri_index(e, f, NV)];
+                c = F16Op<J>::mma(H[e], L[f], c);
+                c = F16Op<J>::mma(L[e], H[f], c);
+                c = F16Op<J>::mma(H[e], H[f], c);
+                G.acc[tri_index(e, f, NV)] = c;
+            }
+    }
 }
 
 template <int NV, int J, bool WIDE>
