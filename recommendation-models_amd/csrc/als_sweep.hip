@@ -478,23 +478,25 @@ __device__ __forceinline__ void gram_mma(Gram<float, NV> &G,
         // The half-depth instruction runs at half the rate of the full-depth one (both take 16
         // cycles).  With a lane's eight contraction slots = its four neighbours twice, one
         // full-depth instruction takes two products of a tile at once:
-        //   [H_e | L_e]^T [L_f | H_f] = H_e^T L_f + L_e^T H_f,   [H_e | L_e]^T [H_f | 0] = H_e^T H_f,
-        // 32 instead of 48 matrix-pipe cycles per tile and block.  The right-hand operands are
-        // put together per tile column (register moves), so that only one pair is live at a
-        // time.  (The second product as a half-depth instruction behind the first gave garbage
-        // in some tiles: two matrix instructions of different depth back to back on one
-        // accumulator.)
-        const f16x4 zero4 = {0, 0, 0, 0};
+        //   [H_e | L_e]^T [L_f | H_f] = H_e^T L_f + L_e^T H_f,
+        //   [H_e | L_e]^T [H_f | L_f] = H_e^T H_f + L_e^T L_f
+        // (the fourth product, which the three-instruction form drops, comes for free): 32
+        // instead of 48 matrix-pipe cycles per tile and block.  [L_f | H_f] is put together per
+        // tile column (four register moves), so that only one is live at a time.  (The second
+        // product as a half-depth instruction behind the first gave garbage in some tiles: two
+        // matrix instructions of different depth back to back on one accumulator.)
+        f16x8 hl[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e)
+            hl[e] = __builtin_shufflevector(H[e], L[e], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int f = 0; f < NV; ++f) {
             const f16x8 lh = __builtin_shufflevector(L[f], H[f], 0, 1, 2, 3, 4, 5, 6, 7);
-            const f16x8 h0 = __builtin_shufflevector(H[f], zero4, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int e = 0; e <= f; ++e) {
-                const f16x8 hl = __builtin_shufflevector(H[e], L[e], 0, 1, 2, 3, 4, 5, 6, 7);
                 Mfma<float>::acc_t c = G.acc[tri_index(e, f, NV)];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hl, lh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hl, h0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hl[e], lh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hl[e], hl[f], c, 0, 0, 0);
                 G.acc[tri_index(e, f, NV)] = c;
             }
         }
