@@ -1191,17 +1191,28 @@ struct PivotBlock {
 #pragma unroll
             for (int j = K + 1; j < NV; ++j) zs[j] = split_tile(G.acc[tri_index(K, j, NV)], sd);
             split_fence();
-            // product by product over all tiles, so that consecutive matrix instructions do not
-            // wait on each other's accumulator
+            // Two full-depth instructions per tile, [h|l]^T[l'|h'] and [h|l]^T[h'|l'] (all four
+            // products of the split; the contraction index doubled by concatenation, as in the
+            // Gram build at padded rank 128), product by product over all tiles, so that
+            // consecutive matrix instructions do not wait on each other's accumulator.
+            f16x8 hl[NV];
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int j = K + 1; j < NV; ++j)
+                hl[j] = __builtin_shufflevector(zs[j].h, zs[j].l, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int term = 0; term < 2; ++term)
 #pragma unroll
                 for (int i = K + 1; i < NV; ++i) {
-                    const f16x4 a = negate(term == 1 ? zs[i].l : zs[i].h);
+                    const f16x8 a = __builtin_shufflevector(negate(zs[i].h), negate(zs[i].l), 0, 1,
+                                                            2, 3, 4, 5, 6, 7);
 #pragma unroll
-                    for (int j = i; j < NV; ++j)
-                        G.acc[tri_index(i, j, NV)] = __builtin_amdgcn_mfma_f32_16x16x16f16(
-                            a, term == 0 ? zs[j].l : zs[j].h, G.acc[tri_index(i, j, NV)], 0, 0, 0);
+                    for (int j = i; j < NV; ++j) {
+                        const f16x8 b = term == 0 ? __builtin_shufflevector(zs[j].l, zs[j].h, 0, 1,
+                                                                            2, 3, 4, 5, 6, 7)
+                                                  : hl[j];
+                        G.acc[tri_index(i, j, NV)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            a, b, G.acc[tri_index(i, j, NV)], 0, 0, 0);
+                    }
                 }
         }
 #pragma unroll
