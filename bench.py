@@ -329,7 +329,7 @@ def main():
         e64, u64, i64, _, r64 = timed_sweeps(eng64, 3, 1, fused, barrier, cuda)
         b64 = half_sweep_bytes(eng64.csr.nnz, eng64.csr.n_rows, eng64.kp, 8) + \
             half_sweep_bytes(eng64.csc.nnz, eng64.csc.n_rows, eng64.kp, 8)
-        f64 = {'dtype': 'f64 (v_mfma_f64_16x16x4 Gram, in-register Gauss-Jordan solve)',
+        f64 = {'dtype': 'f64 (v_mfma_f64_16x16x4 Gram, block LDL^T solve on the accumulator tiles)',
                'ms_per_step': e64 / 3 * 1e3, 'sweeps_per_sec': 3 / e64,
                'user_ms': u64 * 1e3, 'item_ms': i64 * 1e3,
                'roofline_frac': b64 / (u64 + i64) / 1e9 / HBM_PEAK_GBS,

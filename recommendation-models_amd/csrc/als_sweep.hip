@@ -1590,20 +1590,28 @@ constexpr int DUAL_MAX_DEG = 64;
 
 // LDS elements one wave needs: the small transposition stage on the fast path (padded rank
 // <= 64, no dump), the whole matrix otherwise.
+// fp64: smallest padded rank solved by the block LDL^T on the accumulator tiles (block_solve_d)
+// instead of the Gauss-Jordan elimination with one matrix row per lane.
+#ifndef F64_BLOCK_MIN_KP
+#define F64_BLOCK_MIN_KP 64
+#endif
 template <typename T, int KP, bool DUMP>
 struct WaveLds {
     static constexpr bool FAST = !DUMP && KP <= 128;
     // work area: block-solver paths (fp32; fp64 at padded rank 128) = the row's current vector
     // (error variant) only; fp64 Gauss-Jordan path = the transposition stage; otherwise (the
     // dump) the whole matrix
-    static constexpr bool BLOCK = sizeof(T) == 4 || KP == 128;
+    static constexpr bool BLOCK = sizeof(T) == 4 || KP >= F64_BLOCK_MIN_KP;
     static constexpr int WORK = FAST ? (BLOCK ? KP : Stage<T, KP < 64 ? KP : 64>::ELEMS)
                                      : Slab<T, KP>::ELEMS;
     // + 64 doubles behind the work area: the lanes' squared-error partial sums
     static constexpr int ERR_AT = (WORK + 1) / 2 * 2;
     // + (padded rank 128) the back-substitution data of the eight pivot blocks
     static constexpr int STASH_AT = ERR_AT + 512 / (int)sizeof(T);
-    static constexpr int ELEMS = STASH_AT + ((KP == 128 && !DUMP) ? 8 * 8 * WAVE : 0);
+    // (fp64: from padded rank F64_BLOCK_MIN_KP on, one 8 x 64 slab per pivot block)
+    static constexpr int STASH_BLOCKS =
+        DUMP ? 0 : (KP == 128 ? 8 : ((sizeof(T) == 8 && KP >= F64_BLOCK_MIN_KP) ? KP / 16 : 0));
+    static constexpr int ELEMS = STASH_AT + STASH_BLOCKS * 8 * WAVE;
     static constexpr size_t BYTES = (size_t)ELEMS * sizeof(T);
 };
 
@@ -1712,7 +1720,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
                 *reinterpret_cast<vec_t *>(out + lane * NV) = v;
             }
             continue;
-        } else if constexpr (FAST && KP == 128) {
+        } else if constexpr (FAST && KP >= F64_BLOCK_MIN_KP) {
             double xs[NV];
             const bool ok = block_solve_d<NV>(G, lane, p.rank, ridge, xs,
                                               reinterpret_cast<double *>(Asm) +
