@@ -342,7 +342,7 @@ __device__ __forceinline__ f16x2 split_low(f16x2 h, float x0, float s0, float x1
 }
 __device__ __forceinline__ void split_fence() {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 1");
+    asm volatile("s_nop 3");  // two wait states are required; two more for margin
     __builtin_amdgcn_sched_barrier(0);
 }
 
