@@ -23,46 +23,122 @@ namespace alsmi {
 constexpr int IMC_MAX_Q = 256;
 constexpr int IMC_KSPLIT = 128;
 
-// ---- C[M x N] (+)= op(A) B with one 16x16 tile per wave on v_mfma_*_16x16x4 --------------
+// ---- C[M x N] = op(A) B on v_mfma_*_16x16x4, a block of TM x TN 16x16 tiles per wave ----------
 // TRANS_A = false: A is [M x K] row-major (lda).  TRANS_A = true: A is [K x M] row-major.
 // B is [K x NB] row-major (ldb) with NB <= N real columns; output columns NB..N-1 are written
 // as zero (that is how a table with a padded row stride gets its zero pad columns).
 // Out-of-range operand elements read as zero, so any M, N, K work.  The K range is cut into
-// gridDim.z slices; slice z writes its tile to C + z * slice_stride (partial results, summed
-// in slice order by reduce_partials_kernel).
-template <typename T, bool TRANS_A>
-__global__ __launch_bounds__(256) void gemm16_kernel(int M, int N, int NB, int64_t K,
-                                                     const T *__restrict__ A, int64_t lda,
-                                                     const T *__restrict__ B, int64_t ldb,
-                                                     T *__restrict__ C, int64_t ldc,
-                                                     int64_t slice_stride) {
+// gridDim.z slices; slice z writes its tiles to C + z * slice_stride (partial results, summed
+// in slice order by reduce_partials_kernel).  A wave loads TM + TN operand values per TM * TN
+// matrix instructions; every tile accumulates over k in a fixed order that does not depend on
+// TM, TN or the grid.
+template <typename T, bool TRANS_A, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_tiles_kernel(int M, int N, int NB, int64_t K,
+                                                         const T *__restrict__ A, int64_t lda,
+                                                         const T *__restrict__ B, int64_t ldb,
+                                                         T *__restrict__ C, int64_t ldc,
+                                                         int64_t slice_stride) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
-    const int tiles_n = (N + 15) >> 4;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t n_tiles = (int64_t)((M + 15) >> 4) * tiles_n;
-    if (tile >= n_tiles) return;
-    const int i0 = (int)(tile / tiles_n) * 16, j0 = (int)(tile % tiles_n) * 16;
+    const int blocks_n = (N + 16 * TN - 1) / (16 * TN);
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_blocks = (int64_t)((M + 16 * TM - 1) / (16 * TM)) * blocks_n;
+    if (blk >= n_blocks) return;
+    const int i0 = (int)(blk / blocks_n) * 16 * TM, j0 = (int)(blk % blocks_n) * 16 * TN;
     const int64_t kslice = (K + gridDim.z - 1) / gridDim.z;
     const int64_t kb = (int64_t)blockIdx.z * kslice;
     const int64_t ke = kb + kslice < K ? kb + kslice : K;
-    typename Mfma<T>::acc_t acc = {0, 0, 0, 0};
-    const bool row_ok = i0 + q < M, col_ok = j0 + q < N, bcol_ok = j0 + q < NB;
-    for (int64_t k0 = kb; k0 < ke; k0 += 4) {
-        const int64_t k = k0 + g;
-        T a = T(0), b = T(0);
-        if (k < ke) {
-            if (row_ok) a = TRANS_A ? A[k * lda + i0 + q] : A[(int64_t)(i0 + q) * lda + k];
-            if (bcol_ok) b = B[k * ldb + j0 + q];
+    typename Mfma<T>::acc_t acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+    bool row_ok[TM], bcol_ok[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) row_ok[tm] = i0 + 16 * tm + q < M;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bcol_ok[tn] = j0 + 16 * tn + q < NB;
+    // Four steps of four k at a time: all their operand loads first, then the matrix
+    // instructions, so that a wave has 4 (TM + TN) values in flight instead of TM + TN.
+    // Within such a group of 16 k, step u of lane group g takes k = k0 + 4 g + u (any fixed
+    // assignment of the k to steps and lane groups will do, the same on both operands): a row
+    // of a row-major A then gives a lane its four values as ONE contiguous load, and the four
+    // lane groups together read 16 contiguous values of the row.
+    constexpr int GEMM_U = 4;
+    const bool a_vec = !TRANS_A && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) % (4 * sizeof(T))) == 0;
+    for (int64_t k0 = kb; k0 < ke; k0 += 4 * GEMM_U) {
+        T a[GEMM_U][TM], b[GEMM_U][TN];
+        const int64_t kg = k0 + 4 * g;  // this lane group's four k
+        if (a_vec && k0 + 4 * GEMM_U <= ke) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                T v4[4] = {T(0), T(0), T(0), T(0)};
+                if (row_ok[tm]) load_vec<T, 4>(v4, A + (int64_t)(i0 + 16 * tm + q) * lda + kg);
+#pragma unroll
+                for (int u = 0; u < GEMM_U; ++u) a[u][tm] = v4[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < GEMM_U; ++u)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    a[u][tm] = T(0);
+                    if (kg + u < ke && row_ok[tm])
+                        a[u][tm] = TRANS_A ? A[(kg + u) * lda + i0 + 16 * tm + q]
+                                           : A[(int64_t)(i0 + 16 * tm + q) * lda + kg + u];
+                }
         }
-        acc = Mfma<T>::mma(a, b, acc);
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                b[u][tn] = T(0);
+                if (kg + u < ke && bcol_ok[tn]) b[u][tn] = B[(kg + u) * ldb + j0 + 16 * tn + q];
+            }
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = Mfma<T>::mma(a[u][tm], b[u][tn], acc[tm][tn]);
     }
     T *Cz = C + (int64_t)blockIdx.z * slice_stride;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = i0 + Mfma<T>::crow(g, r);
-        if (i < M && col_ok) Cz[(int64_t)i * ldc + j0 + q] = acc[r];
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 16 * tm + Mfma<T>::crow(g, r);
+                const int jj = j0 + 16 * tn + q;
+                if (i < M && jj < N) Cz[(int64_t)i * ldc + jj] = acc[tm][tn][r];
+            }
+}
+
+// Launches gemm_tiles_kernel with the tile block that fits the shape (wide outputs 2 x 4 tiles
+// per wave, narrow ones fewer, so that no wave multiplies padding).
+template <typename T, bool TRANS_A>
+static void launch_gemm(int M, int N, int NB, int64_t K, const T *A, int64_t lda, const T *B,
+                        int64_t ldb, T *C, int64_t ldc, int ksplit, int64_t slice_stride,
+                        hipStream_t st) {
+#define ALSMI_GEMM(TM, TN)                                                                       \
+    do {                                                                                         \
+        const int64_t blocks = (int64_t)((M + 16 * TM - 1) / (16 * TM)) *                        \
+                               ((N + 16 * TN - 1) / (16 * TN));                                  \
+        hipLaunchKernelGGL((gemm_tiles_kernel<T, TRANS_A, TM, TN>),                              \
+                           dim3((unsigned)((blocks + 3) / 4), 1, (unsigned)ksplit), dim3(256), 0, \
+                           st, M, N, NB, K, A, lda, B, ldb, C, ldc, slice_stride);               \
+    } while (0)
+    const bool tall = M > 16;
+    if (N > 32) {
+        if (tall) ALSMI_GEMM(2, 4); else ALSMI_GEMM(1, 4);
+    } else if (N > 16) {
+        if (tall) ALSMI_GEMM(2, 2); else ALSMI_GEMM(1, 2);
+    } else {
+        if (tall) ALSMI_GEMM(2, 1); else ALSMI_GEMM(1, 1);
     }
+#undef ALSMI_GEMM
 }
 
 // out[i] = sum_z partials[z * count + i], fixed order.
@@ -283,11 +359,9 @@ static int run_imc_eval(int mode, int64_t n_users, int64_t n_samples, int p, int
     int64_t *border_user = reinterpret_cast<int64_t *>(base + ws.border_user_off);
 
     // A = X M with the padded row stride; M has q real columns, the pad columns come out zero
-    const int64_t tiles_a = ((n_users + 15) / 16) * (ld / 16);
-    hipLaunchKernelGGL((gemm16_kernel<T, false>), dim3((unsigned)((tiles_a + 3) / 4), 1, 1),
-                       dim3(256), 0, st, (int)n_users, ld, q, (int64_t)p,
-                       static_cast<const T *>(X), (int64_t)p, static_cast<const T *>(Mmat),
-                       (int64_t)q, Atab, (int64_t)ld, (int64_t)0);
+    launch_gemm<T, false>((int)n_users, ld, q, (int64_t)p, static_cast<const T *>(X), (int64_t)p,
+                          static_cast<const T *>(Mmat), (int64_t)q, Atab, (int64_t)ld, 1,
+                          (int64_t)0, st);
     ALSMI_HIP_CHECK(hipGetLastError());
 
     // d_e, squared error, W = (weights) x Y in one pass over the stored entries
@@ -323,12 +397,9 @@ static int run_imc_eval(int mode, int64_t n_users, int64_t n_samples, int p, int
         int ksplit = (int)((n_users + 255) / 256);
         if (ksplit > IMC_KSPLIT) ksplit = IMC_KSPLIT;
         if (ksplit < 1) ksplit = 1;
-        const int64_t tiles_o = (int64_t)((p + 15) / 16) * ((q + 15) / 16);
         const int64_t count = (int64_t)p * q;
-        hipLaunchKernelGGL((gemm16_kernel<T, true>),
-                           dim3((unsigned)((tiles_o + 3) / 4), 1, (unsigned)ksplit), dim3(256), 0,
-                           st, p, q, q, n_users, static_cast<const T *>(X), (int64_t)p, Wtab,
-                           (int64_t)ld, part, (int64_t)q, count);
+        launch_gemm<T, true>(p, q, q, n_users, static_cast<const T *>(X), (int64_t)p, Wtab,
+                             (int64_t)ld, part, (int64_t)q, ksplit, count, st);
         ALSMI_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((count + 255) / 256)),
                            dim3(256), 0, st, part, ksplit, count, static_cast<T *>(out));
@@ -364,20 +435,16 @@ int alsmi_imc_project(int dtype, int64_t n_rows, int p, int q, const void *X, co
     if (n_rows == 0) return ALSMI_OK;
     ALSMI_REQUIRE(X && M && table_out, "alsmi_imc_project: null pointer");
     const int ld = imc_ld(q);
-    const int64_t tiles = ((n_rows + 15) / 16) * (ld / 16);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == ALSMI_F32)
-        hipLaunchKernelGGL((gemm16_kernel<float, false>), dim3((unsigned)((tiles + 3) / 4), 1, 1),
-                           dim3(256), 0, st, (int)n_rows, ld, q, (int64_t)p,
-                           static_cast<const float *>(X), (int64_t)p,
-                           static_cast<const float *>(M), (int64_t)q,
-                           static_cast<float *>(table_out), (int64_t)ld, (int64_t)0);
+        launch_gemm<float, false>((int)n_rows, ld, q, (int64_t)p, static_cast<const float *>(X),
+                                  (int64_t)p, static_cast<const float *>(M), (int64_t)q,
+                                  static_cast<float *>(table_out), (int64_t)ld, 1, (int64_t)0, st);
     else
-        hipLaunchKernelGGL((gemm16_kernel<double, false>), dim3((unsigned)((tiles + 3) / 4), 1, 1),
-                           dim3(256), 0, st, (int)n_rows, ld, q, (int64_t)p,
-                           static_cast<const double *>(X), (int64_t)p,
-                           static_cast<const double *>(M), (int64_t)q,
-                           static_cast<double *>(table_out), (int64_t)ld, (int64_t)0);
+        launch_gemm<double, false>((int)n_rows, ld, q, (int64_t)p, static_cast<const double *>(X),
+                                   (int64_t)p, static_cast<const double *>(M), (int64_t)q,
+                                   static_cast<double *>(table_out), (int64_t)ld, 1, (int64_t)0,
+                                   st);
     ALSMI_HIP_CHECK(hipGetLastError());
     return ALSMI_OK;
 }
