@@ -161,10 +161,18 @@ class ImcProblem(object):
     def _eval(self, mode, M, want_out=True, want_sse=False, want_pred=False, ratings=None):
         torch = self._torch
         M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(self.p, self.q))
-        Md = torch.from_numpy(M).to(self.device, self._td)
-        out = torch.zeros((self.p, self.q), dtype=self._td, device=self.device) \
-            if want_out else None
-        sse = torch.zeros(1, dtype=torch.float64, device=self.device) if want_sse else None
+        # the p x q operand and result and the scalar live in buffers kept across evaluations
+        # (an optimiser calls this hundreds of times); only the values cross the host boundary
+        bufs = getattr(self, '_eval_bufs', None)
+        if bufs is None:
+            bufs = self._eval_bufs = (
+                torch.empty((self.p, self.q), dtype=self._td, device=self.device),
+                torch.empty((self.p, self.q), dtype=self._td, device=self.device),
+                torch.empty(1, dtype=torch.float64, device=self.device))
+        Md = bufs[0]
+        Md.copy_(torch.from_numpy(M))
+        out = bufs[1].zero_() if want_out else None
+        sse = bufs[2].zero_() if want_sse else None
         # predictions: this rank fills its samples' slots of the full (grouped) vector
         pred = torch.zeros(self.n_samples, dtype=self._td, device=self.device) \
             if want_pred else None

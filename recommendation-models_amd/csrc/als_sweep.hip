@@ -163,7 +163,10 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E
 #ifndef ALSMI_F64_R128_DEEP
 #define ALSMI_F64_R128_DEEP 4
 #endif
-    constexpr int DEEP = (NV * (int)sizeof(T) <= 16) ? 8 : (NV * (int)sizeof(T) == 64 ? ALSMI_F64_R128_DEEP : 4);
+#ifndef ALSMI_F64_R64_DEEP
+#define ALSMI_F64_R64_DEEP 4
+#endif
+    constexpr int DEEP = (NV * (int)sizeof(T) <= 16) ? 8 : (NV * (int)sizeof(T) == 64 ? ALSMI_F64_R128_DEEP : (sizeof(T) == 8 ? ALSMI_F64_R64_DEEP : 4));
     const int g = lane >> 4, q = lane & 15;
     const T *srcq = src + q * NV;
     int idx_n = 0;
