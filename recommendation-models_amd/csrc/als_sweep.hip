@@ -467,12 +467,13 @@ __device__ __forceinline__ void gram_block_f16(Gram<float, NV> &G, ErrAcc<float,
         }
 }
 
-// The same block in two halves, for the software-pipelined loop of padded rank 128 (two waves
-// per SIMD): gram_fetch issues the block's loads and, once they have arrived, turns them into
-// the operand registers; gram_mma issues the block's matrix instructions.  The loop runs the
+// The same block in two halves, for the software-pipelined loop (padded rank 64 and 128):
+// gram_issue issues the block's loads, gram_convert turns them, once they have arrived, into
+// the operand registers, gram_mma issues the block's matrix instructions.  The loop runs the
 // matrix instructions of block n between the loads of block n+1 and their first use, so that a
-// wave's memory latency and its matrix work overlap (the other wave of the SIMD is in the same
-// loop, or in its solve).
+// wave's memory latency and its matrix work overlap (the other waves of the SIMD are in the
+// same loop, or in their solve).  The loop is not unrolled: at padded rank 64 that also frees
+// the registers the four unrolled blocks of the plain form needed.
 template <int NV, int J>
 __device__ __forceinline__ void gram_mma(Gram<float, NV> &G,
                                          const typename F16Op<J>::vec_t (&H)[NV],
@@ -626,7 +627,12 @@ __device__ __forceinline__ void gram_range_split(Gram<float, NV> &G, ErrAcc<floa
             gram_block32_split<NV, FULL, ERR>(G, E, srcq, idx, rv, off, valid, g);
     };
     constexpr int BLK = is_f16x2(MODE) ? 4 * J : 32;  // neighbours per block
-    constexpr bool PIPE = NV == 8 && is_f16x2(MODE);
+    // software-pipelined from this many 16-dimension blocks on (measured: -2 % at padded rank
+    // 64, -4 % at 128; narrower ranks keep the unrolled plain form)
+#ifndef GRAM_PIPE_MIN_NV
+#define GRAM_PIPE_MIN_NV 4
+#endif
+    constexpr bool PIPE = NV >= GRAM_PIPE_MIN_NV && is_f16x2(MODE);
     // pipelined loop: the operands of the block whose matrix instructions are still to be issued
     typename F16Op<J>::vec_t H[NV], L[NV];
     bool pending = false;
