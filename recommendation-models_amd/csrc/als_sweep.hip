@@ -1123,10 +1123,29 @@ __device__ __forceinline__ float prescale_factor(float dmax) {
     return usable ? __builtin_bit_cast(float, (unsigned)field << 23) : 1.0f;
 }
 
+// Timing build (-DALSMI_PHASE_CLOCK): wave-clock cycles per phase of the fp32 row kernel, summed
+// over all waves into g_phase (read back with alsmi_debug_phase): 0 row header, 1 Gram build,
+// 2 error terms, 3 ridge/prescale, 4 elimination steps, 5 split + trailing updates, 6 back
+// substitution + store, 7 rows.
+#ifdef ALSMI_PHASE_CLOCK
+__device__ unsigned long long g_phase[8];
+#define PHASE_T(var) const long long var = (long long)__builtin_readcyclecounter()
+#define PHASE_ADD(pc, slot, a, b) \
+    do {                          \
+        if (pc) (pc)[slot] += (b) - (a); \
+    } while (0)
+#else
+#define PHASE_T(var)
+#define PHASE_ADD(pc, slot, a, b)
+#endif
+
 // Lane constants of the block solver.
 struct SolveLane {
     int lane, g, q, irow, addr_row, addr_col;
     bool last_col;
+#ifdef ALSMI_PHASE_CLOCK
+    long long *pc;
+#endif
 };
 
 // Forward phase of pivot block K (see above); K is a template parameter so that every tile
@@ -1147,6 +1166,7 @@ struct PivotBlock {
             const float yrow = bperm(4 * (4 * g + r), y[K]);  // column -> row layout
             rt[r] = L.last_col ? yrow : ((4 * g + r == q) ? 1.0f : 0.0f);
         }
+        PHASE_T(tc0);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int gp = p >> 2, rp = p & 3;
@@ -1172,6 +1192,8 @@ struct PivotBlock {
             mfma_f32_fence<1>();
             dv[rp] = (g == gp) ? inv : dv[rp];
         }
+        PHASE_T(tc1);
+        PHASE_ADD(L.pc, 4, tc0, tc1);
         // every pivot positive and finite <=> every reciprocal positive and finite
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad |= (dv[r] > 0.0f && dv[r] < INFINITY) ? 0 : 1;
@@ -1239,6 +1261,8 @@ struct PivotBlock {
                 stash[((K * 8) + 4 + r) * WAVE + L.lane] = zr[K][r];
             }
         }
+        PHASE_T(tc2);
+        PHASE_ADD(L.pc, 5, tc1, tc2);
         PivotBlock<NV, K + 1, TR16>::run(G, L, y, rs, zr, bad, stash);
     }
 };
@@ -1285,7 +1309,9 @@ struct BackBlock {
 // first `rank` of them real) instead of the factor dimensions.
 template <int NV, bool DUAL = false>
 __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int rank, float ridge,
-                                            float (&xc)[NV], float *stash = nullptr) {
+                                            float (&xc)[NV], float *stash = nullptr,
+                                            long long *pc = nullptr) {
+    PHASE_T(ta);
     // The lane-dependent constants below are cheap to derive; hiding the lane id from the
     // optimiser keeps them from being hoisted out of the row loop, where they would occupy
     // registers (or spill slots) throughout the accumulation.
@@ -1298,6 +1324,9 @@ __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int ra
     L.addr_row = 4 * L.q;          // + 64*gp: lane (gp, q)
     L.addr_col = 4 * L.irow;       // + 64*gp: lane (gp, irow)
     L.last_col = L.q == 15;
+#ifdef ALSMI_PHASE_CLOCK
+    L.pc = pc;
+#endif
     if constexpr (DUAL)
         add_ridge_dual<NV>(G, lane, rank, ridge);
     else
@@ -1329,10 +1358,16 @@ __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int ra
     // z_k = inv(L_kk) y_k in the row layout.
     f4 rs[NV], zr[NV];
     int bad = 0;
+    PHASE_T(tb);
+    PHASE_ADD(pc, 3, ta, tb);
     PivotBlock<NV, 0, TR16>::run(G, L, y, rs, zr, bad, stash);
+    PHASE_T(td);
     float chk = 0.0f;
     BackBlock<NV, NV - 1>::run(G, rs, zr, xc, chk, stash, lane);
-    return !__any(bad != 0 || !(chk < INFINITY));
+    const bool all_ok = !__any(bad != 0 || !(chk < INFINITY));
+    PHASE_T(te);
+    PHASE_ADD(pc, 6, td, te);
+    return all_ok;
 }
 
 // ---- fp64 block solver (padded rank 128) --------------------------------------------------------
@@ -1656,7 +1691,14 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
     double *lane_err_slot =
         reinterpret_cast<double *>(Asm + WaveLds<T, KP, DUMP>::ERR_AT) + lane;
     if constexpr (ERR) *lane_err_slot = 0.0;
+#ifdef ALSMI_PHASE_CLOCK
+    long long pcs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long *pc = pcs;
+#else
+    long long *pc = nullptr;
+#endif
     for (int t = p.t_begin + blockIdx.x * WPB + wl; t < p.t_end; t += W) {
+        PHASE_T(t0);
         const int row = p.order[t];
         const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
         T *out = p.dst + (int64_t)row * KP;
@@ -1685,6 +1727,11 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
         const int sf = p.slab_first[t];
         ErrAcc<T, NV, ERR> E;
         E.init();
+#ifdef ALSMI_PHASE_CLOCK
+        asm volatile("" ::"s"(sf), "s"(beg), "s"(end));  // the header's loads end here
+#endif
+        PHASE_T(t1);
+        PHASE_ADD(pc, 0, t0, t1);
         if (sf >= 0) {
             // a long row: sum_slabs_kernel left the sum of its chunks in its first slab
             G.add(p.slabs + (size_t)sf * (Gram<T, NV>::SLAB_SLOTS * WAVE), lane, E.sum);
@@ -1692,11 +1739,15 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             gram_accumulate<T, NV, MODE, ERR>(G, E, p.indices, p.vals, p.src, beg, end, lane,
                                               scale);
         }
+        PHASE_T(t2);
+        PHASE_ADD(pc, 1, t1, t2);
         if constexpr (ERR) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             *lane_err_slot += row_error_part<T, NV>(G, E.sum, Asm, lane, inv_s2);
         }
+        PHASE_T(t3);
+        PHASE_ADD(pc, 2, t2, t3);
         if constexpr (is_f16x2(MODE) && DUMP) {  // show the unscaled system (exact: S^2 = 2^k)
 #pragma unroll
             for (int k = 0; k < Gram<T, NV>::NTRI; ++k) G.acc[k] *= inv_s2;
@@ -1717,7 +1768,7 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             float xs[NV];
             float *stash = nullptr;
             if constexpr (KP == 128) stash = reinterpret_cast<float *>(Asm) + WaveLds<T, KP, DUMP>::STASH_AT;
-            const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs, stash);
+            const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs, stash, pc);
             if (lane < 16) {
                 typedef float vec_t __attribute__((ext_vector_type(NV)));
                 vec_t v;
@@ -1728,6 +1779,9 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
                 }
                 *reinterpret_cast<vec_t *>(out + lane * NV) = v;
             }
+#ifdef ALSMI_PHASE_CLOCK
+            pcs[7] += 1;
+#endif
             continue;
         } else if constexpr (FAST && KP >= F64_BLOCK_MIN_KP) {
             double xs[NV];
@@ -1764,6 +1818,10 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
         const double wave_err = wave_sum(*lane_err_slot);
         if (lane == 0) p.err_part[blockIdx.x * WPB + wl] = wave_err;
     }
+#ifdef ALSMI_PHASE_CLOCK
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase[i], (unsigned long long)pcs[i]);
+#endif
 }
 
 // ---- kernel 2b: short rows in the neighbour-by-neighbour ("dual") form ---------------------
@@ -2520,3 +2578,14 @@ int alsmi_normal_equations(alsmi_plan *pl, const int64_t *indptr, const int32_t 
 }
 
 }  // extern "C"
+
+#ifdef ALSMI_PHASE_CLOCK
+extern "C" int alsmi_debug_phase(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(alsmi::g_phase), 64) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(alsmi::g_phase), z, 64) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif

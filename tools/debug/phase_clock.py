@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Wave-clock cycles per phase of the fp32 row kernel (a library built with -DALSMI_PHASE_CLOCK,
+selected through ALSMI_LIB):  ALSMI_LIB=build/libalsmi_pc.so python tools/debug/phase_clock.py [config]
+Prints, per half-sweep side, the share of each phase in the waves' time and cycles per row."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, 'recommendation-models_amd')):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+import bench
+from alsmi import _lib, synth, device as dev
+from alsmi.engine import AlsEngine
+
+cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else 'c2']
+device = dev.require_gpu()
+prob = synth.sharded_problem(20243, cfg['n'], cfg['m'], cfg['nnz'], 1, 0, device)
+eng = AlsEngine(prob['csr'], prob['csc'], (cfg['n'], cfg['m']), cfg['rank'], 0.1,
+                dtype=np.float32, total_nnz=int(prob['csr'][0][-1]))
+bench.init_factors(eng, cfg['rank'], device)
+lib = _lib.load()
+fn = lib.alsmi_debug_phase
+fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+names = ['header', 'gram', 'error', 'ridge/prescale', 'elimination', 'split+trailing', 'back+store', 'rows']
+def read(reset):
+    buf = (ctypes.c_ulonglong * 8)()
+    assert fn(buf, reset) == 0
+    return np.array(list(buf), dtype=np.float64)
+for _ in range(2):
+    eng.sweep()
+torch.cuda.synchronize()
+for side, call in (('user side (error variant)', lambda: eng.half_sweep_users_err()),
+                   ('user side (plain)', eng.half_sweep_users), ('item side', eng.half_sweep_items)):
+    read(1)
+    call()
+    torch.cuda.synchronize()
+    v = read(1)
+    rows = max(v[7], 1)
+    tot = v[:7].sum()
+    print(side, 'rows in the ld x ld kernel: %d, wave cycles per row %.0f' % (rows, tot / rows))
+    for n, x in zip(names[:7], v[:7]):
+        print('   %-16s %5.1f %%  %8.0f cycles/row' % (n, 100 * x / tot, x / rows))
