@@ -2,7 +2,7 @@
 """IMC evaluation throughput at BASELINE config 3 shape (138 493 x 26 744, 20 M entries,
 users x 128 and items x 256 side features): one cost+gradient evaluation and one
 Hessian-vector product per step, fp64.  Prints one JSON line.  Not the headline bench (that is
-bench.py); used for the per-kernel numbers in DESIGN.md.
+bench.py); gives the per-kernel IMC numbers.
 
     python tools/bench_imc.py [--small] [--steps 5] [--cpu-frac 0.02]
 """
