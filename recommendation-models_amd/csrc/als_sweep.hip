@@ -1623,6 +1623,7 @@ struct SolveArgs {
     T *A_out;
     T *b_out;
     int64_t row_begin;
+    int solve_prio;  // raise the wave's priority for the solve (plans of short rows)
     // squared error of the rows' current vectors (ERR builds only)
     const T *cur;      // table the rows' current vectors are read from (may be dst)
     double *err_part;  // [waves of the grid]
@@ -1768,7 +1769,14 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             float xs[NV];
             float *stash = nullptr;
             if constexpr (KP == 128) stash = reinterpret_cast<float *>(Asm) + WaveLds<T, KP, DUMP>::STASH_AT;
+            // Waves in their solve issue ahead of waves in their Gram build where rows are short
+            // (p.solve_prio, set by the host from the plan's mean row length): the solve is a
+            // chain of dependent steps, the Gram build waits on memory most of the time.
+            // Measured at 138 493 x 26 744, rank 64: user half -4 %; on the item half, whose
+            // long rows are bound by their gather, the same costs 2-3 %.
+            if (p.solve_prio) __builtin_amdgcn_s_setprio(1);
             const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs, stash, pc);
+            if (p.solve_prio) __builtin_amdgcn_s_setprio(0);
             if (lane < 16) {
                 typedef float vec_t __attribute__((ext_vector_type(NV)));
                 vec_t v;
@@ -2131,6 +2139,7 @@ struct alsmi_plan {
     // Tasks [t_dual[k], t_dual[k+1]) have at most 16 (4 - k) entries (and more than 16 (3 - k));
     // t_dual[4] = n_tasks, and all five = n_tasks when the dual form does not apply to the plan.
     int t_dual[5];
+    int solve_prio;  // 1: the plan's rows are short on average (see solve_rows_kernel)
     int32_t *order, *slab_first, *slab_count;
     int64_t *ch_beg, *ch_end;
     void *slabs;
@@ -2146,6 +2155,10 @@ static size_t slab_slots(int kp) {
     const int nv = kp / 16;
     return (size_t)(nv * (nv + 1) / 2 * 4 + nv + 1) * WAVE;
 }
+
+// Plans whose rows hold at most this many entries on average run their solves at raised wave
+// priority (ALSMI_SOLVE_PRIO=0/1 overrides).
+constexpr int64_t SOLVE_PRIO_MAX_MEAN = 384;
 
 // Diagnostic build selected by the environment (fp32, padded rank 64, plain half-sweep only).
 static int ablation() {
@@ -2323,6 +2336,7 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     a.A_out = static_cast<T *>(A_out);
     a.b_out = static_cast<T *>(b_out);
     a.row_begin = pl->row_begin;
+    a.solve_prio = pl->solve_prio;
     a.cur = static_cast<const T *>(cur);
     a.err_part = pl->err_part;
     // Short rows go to the dual-form kernels (fp32, padded rank 128, not for the dump, whose
@@ -2463,6 +2477,11 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     pl->n_chunks = (int)ch_beg.size();
     pl->n_heavy = n_heavy;
     for (int k = 0; k < 5; ++k) pl->t_dual[k] = (int)n;
+    {
+        const int64_t entries = indptr_host[row_end] - indptr_host[row_begin];
+        static const int forced = getenv("ALSMI_SOLVE_PRIO") ? atoi(getenv("ALSMI_SOLVE_PRIO")) : -1;
+        pl->solve_prio = forced >= 0 ? forced : (n > 0 && entries / n <= SOLVE_PRIO_MAX_MEAN ? 1 : 0);
+    }
     if (dtype == ALSMI_F32 && (kp == 128 || kp == 64)) {
         for (int k = 0; k < 4; ++k) {
             // at padded rank 64 the dual form starts at 48 entries (t_dual[0] = t_dual[1])
