@@ -1623,7 +1623,8 @@ struct SolveArgs {
     T *A_out;
     T *b_out;
     int64_t row_begin;
-    int solve_prio;  // raise the wave's priority for the solve (plans of short rows)
+    int solve_prio;  // raise the wave's priority for the solve: bit 0 in the ld x ld kernel
+                     // (plans of short rows), bit 1 in the short-row kernels
     // squared error of the rows' current vectors (ERR builds only)
     const T *cur;      // table the rows' current vectors are read from (may be dst)
     double *err_part;  // [waves of the grid]
@@ -1774,9 +1775,9 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             // chain of dependent steps, the Gram build waits on memory most of the time.
             // Measured at 138 493 x 26 744, rank 64: user half -4 %; on the item half, whose
             // long rows are bound by their gather, the same costs 2-3 %.
-            if (p.solve_prio) __builtin_amdgcn_s_setprio(1);
+            if (p.solve_prio & 1) __builtin_amdgcn_s_setprio(1);
             const bool ok = block_solve<NV>(G, lane, p.rank, ridge, xs, stash, pc);
-            if (p.solve_prio) __builtin_amdgcn_s_setprio(0);
+            if (p.solve_prio & 1) __builtin_amdgcn_s_setprio(0);
             if (lane < 16) {
                 typedef float vec_t __attribute__((ext_vector_type(NV)));
                 vec_t v;
@@ -1793,9 +1794,11 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             continue;
         } else if constexpr (FAST && KP >= F64_BLOCK_MIN_KP) {
             double xs[NV];
+            if (p.solve_prio & 1) __builtin_amdgcn_s_setprio(1);
             const bool ok = block_solve_d<NV>(G, lane, p.rank, ridge, xs,
                                               reinterpret_cast<double *>(Asm) +
                                                   WaveLds<T, KP, DUMP>::STASH_AT);
+            if (p.solve_prio & 1) __builtin_amdgcn_s_setprio(0);
             if (lane < 16) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) out[lane * NV + k] = ok ? xs[k] : 0.0;
@@ -2000,7 +2003,9 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
             w[a] = t;
         }
 #else
+        if (p.solve_prio & 2) __builtin_amdgcn_s_setprio(1);
         const bool ok = block_solve<ND, true>(G, lane, n, p.alpha * (float)n * s2, w);
+        if (p.solve_prio & 2) __builtin_amdgcn_s_setprio(0);
 #endif
         // x = F^T w: this lane's neighbours again (a lane past the row's end re-reads the
         // row's first neighbour with a zero weight), 8 dimensions of each chunk; then the sum
@@ -2139,7 +2144,8 @@ struct alsmi_plan {
     // Tasks [t_dual[k], t_dual[k+1]) have at most 16 (4 - k) entries (and more than 16 (3 - k));
     // t_dual[4] = n_tasks, and all five = n_tasks when the dual form does not apply to the plan.
     int t_dual[5];
-    int solve_prio;  // 1: the plan's rows are short on average (see solve_rows_kernel)
+    int solve_prio;  // bit 0: the plan's rows are short on average (see solve_rows_kernel);
+                     // bit 1: the short-row kernels raise their priority too (always, -1 %)
     int32_t *order, *slab_first, *slab_count;
     int64_t *ch_beg, *ch_end;
     void *slabs;
@@ -2157,7 +2163,7 @@ static size_t slab_slots(int kp) {
 }
 
 // Plans whose rows hold at most this many entries on average run their solves at raised wave
-// priority (ALSMI_SOLVE_PRIO=0/1 overrides).
+// priority (ALSMI_SOLVE_PRIO=0..3 overrides: bit 0 the ld x ld kernel, bit 1 the short-row kernels).
 constexpr int64_t SOLVE_PRIO_MAX_MEAN = 384;
 
 // Diagnostic build selected by the environment (fp32, padded rank 64, plain half-sweep only).
@@ -2480,7 +2486,7 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     {
         const int64_t entries = indptr_host[row_end] - indptr_host[row_begin];
         static const int forced = getenv("ALSMI_SOLVE_PRIO") ? atoi(getenv("ALSMI_SOLVE_PRIO")) : -1;
-        pl->solve_prio = forced >= 0 ? forced : (n > 0 && entries / n <= SOLVE_PRIO_MAX_MEAN ? 1 : 0);
+        pl->solve_prio = forced >= 0 ? forced : ((n > 0 && entries / n <= SOLVE_PRIO_MAX_MEAN ? 1 : 0) | 2);
     }
     if (dtype == ALSMI_F32 && (kp == 128 || kp == 64)) {
         for (int k = 0; k < 4; ++k) {
