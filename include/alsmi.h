@@ -85,8 +85,9 @@ int alsmi_plan_info(const alsmi_plan *plan, int64_t *n_rows, int64_t *n_heavy_ro
  * relative to themselves only.  An fp32 source table above 4 GiB is accepted
  * at padded rank 128 (64-bit gather addresses are switched in) and rejected
  * with ALSMI_EINVAL at padded rank <= 64 (more than 16.7 M rows).  At padded
- * rank 64 / 128 rows of at most 48 / 64 stored entries are solved in the
- * equivalent n x n form x = F^T (F F^T + alpha n I)^-1 vals; with alpha = 0
+ * rank 64 / 128 rows of at most 48 / 64 stored entries — and never more than
+ * `rank` of them — are solved in the equivalent n x n form
+ * x = F^T (F F^T + alpha n I)^-1 vals; with alpha = 0
  * such a row gets the minimum-norm least-squares solution where the rank x rank
  * matrix of the reference is singular.  Results are bit-reproducible from run
  * to run. */

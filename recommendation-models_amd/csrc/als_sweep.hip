@@ -2489,9 +2489,13 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
         pl->solve_prio = forced >= 0 ? forced : ((n > 0 && entries / n <= SOLVE_PRIO_MAX_MEAN ? 1 : 0) | 2);
     }
     if (dtype == ALSMI_F32 && (kp == 128 || kp == 64)) {
+        // The n x n form is used for rows of at most 48 (padded rank 64) / 64 (128) entries AND
+        // at most `rank` entries: with more entries than dimensions F F^T is rank deficient, its
+        // condition number is that of the ridge alone, and fp32 loses rows the rank x rank
+        // form solves easily (found at rank 33 with rows of 34 to 48 entries).
+        const int64_t dual_max = std::min<int64_t>(kp == 64 ? 48 : alsmi::DUAL_MAX_DEG, rank);
         for (int k = 0; k < 4; ++k) {
-            // at padded rank 64 the dual form starts at 48 entries (t_dual[0] = t_dual[1])
-            const int64_t deg = alsmi::DUAL_MAX_DEG - 16 * (kp == 64 && k == 0 ? 1 : k);
+            const int64_t deg = std::min<int64_t>(alsmi::DUAL_MAX_DEG - 16 * k, dual_max);
             pl->t_dual[k] = (int)(std::partition_point(order.begin(), order.end(), [&](int32_t r) {
                                       return indptr_host[r + 1] - indptr_host[r] > deg;
                                   }) - order.begin());

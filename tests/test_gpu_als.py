@@ -125,6 +125,43 @@ def test_half_sweep_with_error_of_replaced_factors(gpu, case, dtype):
     plan.close()
 
 
+@pytest.mark.parametrize('rank,kp_rows', [(33, (34, 48)), (40, (41, 48)), (70, (40, 64))])
+def test_rows_with_more_entries_than_dimensions_are_not_lost(gpu, rank, kp_rows):
+    """Rows whose entry count lies between the rank and the largest size of the n x n
+    ("dual") form must take the rank x rank form: with more entries than dimensions F F^T is
+    rank deficient and, with large factors and a small ridge, its fp32 factorisation meets
+    non-positive pivots and the row came back as zeros although the reference's matrix is
+    well conditioned (found by tests/fuzz_half_sweep.py at rank 33).  The third case checks
+    that rows the dual form may take (at most `rank` entries) are solved as before."""
+    device, torch = gpu
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    n, m = 150, 430
+    P = random_problem(77 + rank, n, m, n * 43, rank)
+    deg = np.diff(P['indptr'])
+    assert ((deg >= kp_rows[0]) & (deg <= kp_rows[1])).sum() > 20
+    alpha = 0.003
+    V = P['V'] * 1000.0
+    side = dev.SparseSide(P['indptr'], P['indices'], P['vals'], n, m, 'float32', device)
+    plan = dev.SweepPlan(side, rank)
+    Vd = dev.factors_to_device(V, 'float32', device)
+    Vq = dev.factors_to_host(Vd, rank)
+    U = torch.full((n, dev.padded_rank(rank)), 7.0, dtype=Vd.dtype, device=device)
+    plan.half_sweep(Vd, U, alpha)
+    got = dev.factors_to_host(U, rank)
+    want = ao.half_sweep(P['indptr'], P['indices'], P['vals'], Vq, rank, alpha)
+    for r in range(n):
+        lo, hi = P['indptr'][r], P['indptr'][r + 1]
+        if hi - lo < rank:
+            continue  # fewer entries than dimensions: conditioned by the ridge alone
+        S = Vq[:, P['indices'][lo:hi]]
+        cond = np.linalg.cond(S.dot(S.T) + alpha * (hi - lo) * np.eye(rank))
+        assert got[:, r].any(), (r, hi - lo, cond)
+        err = np.linalg.norm(got[:, r] - want[:, r]) / np.linalg.norm(want[:, r])
+        assert err < 50 * cond * 2.0 ** -24, (r, hi - lo, cond, err)
+    plan.close()
+
+
 @pytest.mark.parametrize('dtype,rank', [('float32', 64), ('float32', 20), ('float32', 128),
                                         ('float64', 64)])
 def test_half_sweep_is_reproducible(gpu, dtype, rank):
