@@ -117,6 +117,29 @@ __device__ __forceinline__ double row_error_part(const Gram<T, NV> &G, T r2,
     return (double)r2 - 2.0 * (double)ub + (double)(quad * inv_s2);
 }
 
+// fp64 at padded rank 128 has 36 accumulator tiles of 8 registers, the accumulator file holds
+// 32 of them.  The compiler gives every matrix instruction of a function an accumulator-file
+// destination and then moves the four tiles that do not fit in and out of it around each
+// instruction (16 moves and a wait for the result per use).  Those four tiles (the last four
+// of the triangle) take the same instruction with a vector-register destination instead, which
+// only inline assembly can ask for.  The compiler does not see a matrix instruction in it and
+// adds none of the wait states its result needs before another instruction may touch it
+// (19 for this one), so they are part of the statement; they pass while the matrix pipe works on
+// the instruction (64 cycles) and cost nothing.
+#ifndef F64_VDST_TILES
+#define F64_VDST_TILES 4
+#endif
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 mfma_f64_vdst(double a, double b, f64x4 c) {
+    asm("s_nop 1\n\t"  // a vector instruction may just have written an operand
+        "v_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\t"
+        "s_nop 15\n\t"
+        "s_nop 3"
+        : "+v"(c)
+        : "v"(a), "v"(b));
+    return c;
+}
+
 // One k=4 MFMA step: four neighbours (one per lane group), all upper tiles.
 template <typename T, int NV>
 __device__ __forceinline__ void gram_step(Gram<T, NV> &G, const T (&v)[NV], T rv) {
@@ -125,8 +148,17 @@ __device__ __forceinline__ void gram_step(Gram<T, NV> &G, const T (&v)[NV], T rv
 #pragma unroll
     for (int e = 0; e < NV; ++e)
 #pragma unroll
-        for (int f = e; f < NV; ++f)
+        for (int f = e; f < NV; ++f) {
+            constexpr int NTRI = Gram<T, NV>::NTRI;
+            if constexpr (sizeof(T) == 8 && NV == 8) {
+                if (tri_index(e, f, NV) >= NTRI - F64_VDST_TILES) {
+                    G.acc[tri_index(e, f, NV)] =
+                        mfma_f64_vdst(v[e], v[f], G.acc[tri_index(e, f, NV)]);
+                    continue;
+                }
+            }
             G.acc[tri_index(e, f, NV)] = Mfma<T>::mma(v[e], v[f], G.acc[tri_index(e, f, NV)]);
+        }
 }
 
 // U consecutive k=4 steps starting at step s: issue all their gathers first, then the MFMAs.
@@ -175,6 +207,17 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E
         idx_n = indices[beg + lane];
         rv_n = vals[beg + lane];
     }
+    // fp64 from this many 16-dimension blocks on: software-pipelined in units of PU steps.  The
+    // kernel then runs one wave per SIMD (288 accumulator registers at padded rank 128) and
+    // nothing else hides the gather's latency: the loads of unit k+1 are issued before the
+    // matrix instructions of unit k, across the 64-entry index blocks of the row.
+#ifndef F64_PIPE_MIN_NV
+#define F64_PIPE_MIN_NV 8
+#endif
+    constexpr bool PIPE = sizeof(T) == 8 && NV >= F64_PIPE_MIN_NV;
+    constexpr int PU = 2;
+    T pv[PIPE ? PU : 1][NV], pr[PIPE ? PU : 1];  // the unit whose matrix instructions are due
+    bool pending = false;
     for (int64_t base = beg; base < end; base += WAVE) {
         const int64_t left = end - base;
         const int cnt = left < WAVE ? (int)left : WAVE;
@@ -189,6 +232,54 @@ __device__ __forceinline__ void gram_range(Gram<T, NV> &G, ErrAcc<T, NV, ERR> &E
         }
         const int nfull = cnt >> 2;
         int s = 0;
+        if constexpr (PIPE) {
+            const int nunits = nfull / PU;
+            // the row's last block ends with one more turn that only drains the pipeline
+            const int turns = nunits + (left <= WAVE ? 1 : 0);
+#pragma unroll 1
+            for (int k = 0; k < turns; ++k) {
+                T v[PU][NV], r[PU];
+                const bool fetch = k < nunits;
+                if (fetch) {
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        const int sl = 4 * (k * PU + u) + g;
+                        const int id = __shfl(idx, sl);
+                        r[u] = __shfl(rv, sl);
+                        load_vec<T, NV>(v[u], srcq + (int64_t)id * KP);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (pending) {
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) gram_step<T, NV>(G, pv[u], pr[u]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (fetch) {
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        pr[u] = r[u];
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) pv[u][e] = v[u][e];
+                    }
+                }
+                pending = fetch;
+            }
+            // what is left of the row's last block: at most PU - 1 whole steps and a partial one
+#pragma unroll 1
+            for (s = nunits * PU; 4 * s < cnt; ++s) {
+                const int sl = 4 * s + g;
+                const int id = __shfl(idx, sl);
+                const T r1 = __shfl(rv, sl);
+                T v[NV];
+                load_vec<T, NV>(v, srcq + (int64_t)id * KP);
+                const bool valid = sl < cnt;
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = valid ? v[e] : T(0);
+                gram_step<T, NV>(G, v, r1);
+            }
+            continue;
+        }
         for (; s + DEEP <= nfull; s += DEEP)
             gram_steps<T, NV, DEEP, ERR>(G, E, srcq, idx, rv, s, g);
         if constexpr (DEEP > 4) {
@@ -1400,9 +1491,59 @@ __device__ __forceinline__ double row_allreduce_d(double v) {
     v = dpp_add_d<0x140>(v);
     return v;
 }
+// Cross-lane moves of the fp64 solver on the vector ALU instead of ds_bpermute: the four waves of
+// a CU share one LDS pipe, and at one wave per SIMD the solver's permutes (two per double) kept
+// it busy for most of the solve.
+// v of lane P of this lane's row of 16 (DPP row_newbcast)
+template <int P>
+__device__ __forceinline__ double row_lane_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x150 + P, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + P, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double row_lane_d(double v, int p) {  // p: known after unrolling
+    switch (p) {
+        case 0: return row_lane_d<0>(v);
+        case 1: return row_lane_d<1>(v);
+        case 2: return row_lane_d<2>(v);
+        case 3: return row_lane_d<3>(v);
+        case 4: return row_lane_d<4>(v);
+        case 5: return row_lane_d<5>(v);
+        case 6: return row_lane_d<6>(v);
+        case 7: return row_lane_d<7>(v);
+        case 8: return row_lane_d<8>(v);
+        case 9: return row_lane_d<9>(v);
+        case 10: return row_lane_d<10>(v);
+        case 11: return row_lane_d<11>(v);
+        case 12: return row_lane_d<12>(v);
+        case 13: return row_lane_d<13>(v);
+        case 14: return row_lane_d<14>(v);
+        default: return row_lane_d<15>(v);
+    }
+}
+// v + v of lane ^ 16 (v_permlane16_swap: row 1 of the first operand changes places with row 0 of
+// the second, row 3 with row 2), then + that of lane ^ 32 (v_permlane32_swap: the upper half of
+// the first operand with the lower half of the second); the sums in the order of the former
+// shuffles, bit for bit
 __device__ __forceinline__ double col_allreduce_d(double v) {
-    v += shfl_d(v, (int)(__lane_id() ^ 16));
-    v += shfl_d(v, (int)(__lane_id() ^ 32));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+        const u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        const double even = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+        const double odd = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+        v = even + odd;
+    }
+    {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+        const u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        const double lower = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+        const double upper = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+        v = lower + upper;
+    }
     return v;
 }
 __device__ __forceinline__ d4 mfma_xty_d(d4 x, d4 y, d4 c) {
@@ -1415,6 +1556,12 @@ __device__ __forceinline__ d4 mfma_xty_d(d4 x, d4 y, d4 c) {
     return c;
 }
 
+// (look-ahead order of the elimination steps from this many 16-dimension blocks on: below, two
+// or three waves share a SIMD, hide the latency for each other, and the extra registers would
+// cost one of them)
+#ifndef F64_LOOKAHEAD_MIN_NV
+#define F64_LOOKAHEAD_MIN_NV 8
+#endif
 template <int NV, int K>
 struct PivotBlockD {
     static __device__ __forceinline__ void run(Gram<double, NV> &G, int lane, double (&y)[NV],
@@ -1429,45 +1576,111 @@ struct PivotBlockD {
             const double yrow = shfl_d(y[K], g + 4 * r);  // column -> row layout
             rt[r] = last_col ? yrow : ((g + 4 * r == q) ? 1.0 : 0.0);
         }
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int gp = p & 3, rp = p >> 2;  // row p: lane group gp, register rp
+        if constexpr (NV >= F64_LOOKAHEAD_MIN_NV) {
+            // Step p needs the pivot, its column of the diagonal tile and row p of every tile of the
+            // block row, all of them shaped by step p-1.  One wave per SIMD has nothing to hide the
+            // cross-lane latency behind but its own work, so step p updates first what step p+1
+            // fetches (the diagonal tile, and register (p+1)/4 of the other tiles), issues those
+            // fetches, and applies the other three quarters of its update while they travel.
             d4 &a = G.acc[tri_index(K, K, NV)];
-            const double d = read_lane(a[rp], 16 * gp + p);
-            const double inv = 1.0 / d;
-            double m[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // rows at or above the pivot (compile-time known for most r) keep a zero
-                if (4 * r + 3 <= p) {
-                    m[r] = 0.0;
-                } else {
-                    const double colv = shfl_d(a[r], 16 * g + p);  // A[g + 4r][p]
-                    m[r] = (g + 4 * r > p) ? -colv * inv : 0.0;
-                }
-            }
-            double rows[NV + 1];
-#pragma unroll
-            for (int j = K; j < NV; ++j) rows[j] = shfl_d(G.acc[tri_index(K, j, NV)][rp], 16 * gp + q);
-            rows[NV] = shfl_d(rt[rp], 16 * gp + q);
-#pragma unroll
-            for (int j = K; j < NV; ++j) {
-                d4 &t = G.acc[tri_index(K, j, NV)];
+            double inv, colv[4], rows[NV + 1];
+            auto fetch = [&](int p, double &inv_o, double (&colv_o)[4], double (&rows_o)[NV + 1]) {
+                const int gp = p & 3, rp = p >> 2;  // row p: lane group gp, register rp
+                const double d = read_lane(a[rp], 16 * gp + p);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * r + 3 > p) t[r] = fma(m[r], rows[j], t[r]);
-            }
+                    if (4 * r + 3 > p) colv_o[r] = row_lane_d(a[r], p);  // A[g + 4r][p]
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * r + 3 > p) rt[r] = fma(m[r], rows[NV], rt[r]);
-            dv[rp] = (g == gp) ? inv : dv[rp];
+                for (int j = K; j < NV; ++j)
+                    rows_o[j] = shfl_d(G.acc[tri_index(K, j, NV)][rp], 16 * gp + q);
+                rows_o[NV] = shfl_d(rt[rp], 16 * gp + q);
+                inv_o = 1.0 / d;
+            };
+            fetch(0, inv, colv, rows);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int gp = p & 3, rp = p >> 2;
+                const int rn = (p + 1) >> 2;  // the register the next step's row lives in
+                double m[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)  // rows at or above the pivot keep a zero
+                    m[r] = (4 * r + 3 > p && g + 4 * r > p) ? -colv[r] * inv : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + 3 > p) a[r] = fma(m[r], rows[K], a[r]);
+                if (p < 15 && 4 * rn + 3 > p) {
+#pragma unroll
+                    for (int j = K + 1; j < NV; ++j) {
+                        d4 &t = G.acc[tri_index(K, j, NV)];
+                        t[rn] = fma(m[rn], rows[j], t[rn]);
+                    }
+                    rt[rn] = fma(m[rn], rows[NV], rt[rn]);
+                }
+                double inv_n = 0.0, colv_n[4], rows_n[NV + 1];
+                __builtin_amdgcn_sched_barrier(0);
+                if (p < 15) fetch(p + 1, inv_n, colv_n, rows_n);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = K + 1; j < NV; ++j) {
+                    d4 &t = G.acc[tri_index(K, j, NV)];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * r + 3 > p && !(p < 15 && r == rn)) t[r] = fma(m[r], rows[j], t[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + 3 > p && !(p < 15 && r == rn)) rt[r] = fma(m[r], rows[NV], rt[r]);
+                dv[rp] = (g == gp) ? inv : dv[rp];
+                __builtin_amdgcn_sched_barrier(0);
+                if (p < 15) {
+                    inv = inv_n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) colv[r] = colv_n[r];
+#pragma unroll
+                    for (int j = K; j <= NV; ++j) rows[j] = rows_n[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int gp = p & 3, rp = p >> 2;  // row p: lane group gp, register rp
+                d4 &a = G.acc[tri_index(K, K, NV)];
+                const double d = read_lane(a[rp], 16 * gp + p);
+                const double inv = 1.0 / d;
+                double m[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // rows at or above the pivot (compile-time known for most r) keep a zero
+                    if (4 * r + 3 <= p) {
+                        m[r] = 0.0;
+                    } else {
+                        const double colv = row_lane_d(a[r], p);  // A[g + 4r][p]
+                        m[r] = (g + 4 * r > p) ? -colv * inv : 0.0;
+                    }
+                }
+                double rows[NV + 1];
+#pragma unroll
+                for (int j = K; j < NV; ++j) rows[j] = shfl_d(G.acc[tri_index(K, j, NV)][rp], 16 * gp + q);
+                rows[NV] = shfl_d(rt[rp], 16 * gp + q);
+#pragma unroll
+                for (int j = K; j < NV; ++j) {
+                    d4 &t = G.acc[tri_index(K, j, NV)];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * r + 3 > p) t[r] = fma(m[r], rows[j], t[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + 3 > p) rt[r] = fma(m[r], rows[NV], rt[r]);
+                dv[rp] = (g == gp) ? inv : dv[rp];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad |= (dv[r] > 0.0 && dv[r] < (double)INFINITY) ? 0 : 1;
         d4 dz, zr, rs;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            zr[r] = shfl_d(rt[r], 16 * g + 15);  // z from lane 15 of each lane group
+            zr[r] = row_lane_d<15>(rt[r]);  // z from lane 15 of each lane group
             dz[r] = dv[r] * zr[r];
             const double rtrue = last_col ? ((g + 4 * r == 15) ? 1.0 : 0.0) : rt[r];
             rs[r] = dv[r] * rtrue;
