@@ -1546,6 +1546,36 @@ __device__ __forceinline__ double col_allreduce_d(double v) {
     }
     return v;
 }
+// v of the four lanes with this lane's q (one per lane group), in every one of them
+__device__ __forceinline__ void col_gather_d(double v, double (&out)[4]) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned w[2] = {(unsigned)b, (unsigned)(b >> 32)};
+    unsigned o[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // rows (0,1,0,1) and rows (2,3,2,3), then each of the four rows in all four
+        const u2 s = __builtin_amdgcn_permlane32_swap(w[h], w[h], false, false);
+        const u2 e = __builtin_amdgcn_permlane16_swap(s[0], s[0], false, false);
+        const u2 f = __builtin_amdgcn_permlane16_swap(s[1], s[1], false, false);
+        o[0][h] = e[0];
+        o[1][h] = e[1];
+        o[2][h] = f[0];
+        o[3][h] = f[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        out[k] = __builtin_bit_cast(double, ((unsigned long long)o[k][1] << 32) | o[k][0]);
+}
+// 1/d of a pivot by v_rcp_f64 and three Newton steps (an ulp or two off the rounded quotient,
+// a third of the instructions of the division; zero, denormal and non-finite pivots give values
+// that the solver's pivot and result checks reject)
+__device__ __forceinline__ double rcp_d(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
 __device__ __forceinline__ d4 mfma_xty_d(d4 x, d4 y, d4 c) {
     // (scheduling fences: without them the scaled operands of all the tile updates of a block
     // are formed up front, which costs more registers than there are)
@@ -1556,16 +1586,84 @@ __device__ __forceinline__ d4 mfma_xty_d(d4 x, d4 y, d4 c) {
     return c;
 }
 
-// (look-ahead order of the elimination steps from this many 16-dimension blocks on: below, two
-// or three waves share a SIMD, hide the latency for each other, and the extra registers would
-// cost one of them)
-#ifndef F64_LOOKAHEAD_MIN_NV
-#define F64_LOOKAHEAD_MIN_NV 8
+// (the four-pivot form of the elimination, pivot4() below, from this many 16-dimension blocks
+// on: below, three waves share a SIMD and hide the cross-lane latency of the pivot-by-pivot form
+// for each other, and the registers of the four-pivot form would cost one of them)
+#ifndef F64_PIVOT4_MIN_NV
+#define F64_PIVOT4_MIN_NV 8
 #endif
 template <int NV, int K>
 struct PivotBlockD {
+    // four pivots (rows 4B .. 4B+3 of the block row) at a time, see run()
+    template <int B>
+    static __device__ __forceinline__ void pivot4(Gram<double, NV> &G, int g, int q, d4 &rt,
+                                                  d4 &dv, int &bad) {
+            d4 &a = G.acc[tri_index(K, K, NV)];
+            double c[4];
+            col_gather_d(a[B], c);  // c[k] = A[4b+k][q]
+            const double a00 = row_lane_d<4 * B>(c[0]);
+            const double a10 = row_lane_d<4 * B>(c[1]), a11 = row_lane_d<4 * B + 1>(c[1]);
+            const double a20 = row_lane_d<4 * B>(c[2]), a21 = row_lane_d<4 * B + 1>(c[2]);
+            const double a22 = row_lane_d<4 * B + 2>(c[2]);
+            const double a30 = row_lane_d<4 * B>(c[3]), a31 = row_lane_d<4 * B + 1>(c[3]);
+            const double a32 = row_lane_d<4 * B + 2>(c[3]), a33 = row_lane_d<4 * B + 3>(c[3]);
+            const double i0 = rcp_d(a00);
+            const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+            const double d1 = fma(-l10, a10, a11);
+            const double i1 = rcp_d(d1);
+            const double t21 = fma(-l20, a10, a21), t31 = fma(-l30, a10, a31);
+            const double l21 = t21 * i1, l31 = t31 * i1;
+            const double d2 = fma(-l21, t21, fma(-l20, a20, a22));
+            const double i2 = rcp_d(d2);
+            const double t32 = fma(-l31, t21, fma(-l30, a20, a32));
+            const double l32 = t32 * i2;
+            const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a30, a33)));
+            const double i3 = rcp_d(d3);
+            const double dmin = fmin(fmin(a00, d1), fmin(d2, d3));
+            const double dmax = fmax(fmax(a00, d1), fmax(d2, d3));
+            bad |= ((dmin > 0.0) & (dmax < (double)INFINITY)) ? 0 : 1;
+            asm volatile("" : "+v"(bad));  // (decided here, not from sixteen pivots kept until the end)
+            // A11 x = c for this lane's column q
+            const double y0 = c[0];
+            const double y1 = fma(-l10, y0, c[1]);
+            const double y2 = fma(-l21, y1, fma(-l20, y0, c[2]));
+            const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, c[3])));
+            const double x3 = y3 * i3;
+            const double x2 = fma(-l32, x3, y2 * i2);
+            const double x1 = fma(-l31, x3, fma(-l21, x2, y1 * i1));
+            const double x0 = fma(-l30, x3, fma(-l20, x2, fma(-l10, x1, y0 * i0)));
+            const double xg = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
+            // inv(L) - I, row q - 4b, column g
+            const double m10 = -l10, m21 = -l21, m32 = -l32;
+            const double m20 = -fma(l21, m10, l20), m31 = -fma(l32, m21, l31);
+            const double m30 = -fma(l32, m20, fma(l31, m10, l30));
+            double w1 = g == 0 ? m10 : 0.0;
+            double w2 = g == 0 ? m20 : (g == 1 ? m21 : 0.0);
+            double w3 = g == 0 ? m30 : (g == 1 ? m31 : (g == 2 ? m32 : 0.0));
+            // (both kinds of multiplier exist in every lane before the choice: left to itself the
+            // compiler turns the choice into branches on the lane's q around their computation)
+            double xs = -xg;
+            asm volatile("" : "+v"(xs), "+v"(w1), "+v"(w2), "+v"(w3));
+            const int k = q - 4 * B;
+            // (one choice per candidate, joined by OR: a chain of choices on k becomes a switch)
+            auto pick = [](bool on, double v) {
+                return on ? __builtin_bit_cast(unsigned long long, v) : 0ull;
+            };
+            const double w = __builtin_bit_cast(
+                double, pick(k > 3, xs) | pick(k == 1, w1) | pick(k == 2, w2) | pick(k == 3, w3));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = K; j < NV; ++j) {
+                d4 &t = G.acc[tri_index(K, j, NV)];
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(w, t[B], t, 0, 0, 0);
+            }
+            rt = __builtin_amdgcn_mfma_f64_16x16x4f64(w, rt[B], rt, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dv[B] = g == 0 ? i0 : (g == 1 ? i1 : (g == 2 ? i2 : i3));
+    }
     static __device__ __forceinline__ void run(Gram<double, NV> &G, int lane, double (&y)[NV],
-                                               int &bad, double *stash) {
+                                               int &bad, double *stash, long long *pc) {
+        PHASE_T(tc0);
         const int g = lane >> 4, q = lane & 15;
         const bool last_col = q == 15;
         // R starts as the identity; its last column, which no row operation changes, carries the
@@ -1576,70 +1674,24 @@ struct PivotBlockD {
             const double yrow = shfl_d(y[K], g + 4 * r);  // column -> row layout
             rt[r] = last_col ? yrow : ((g + 4 * r == q) ? 1.0 : 0.0);
         }
-        if constexpr (NV >= F64_LOOKAHEAD_MIN_NV) {
-            // Step p needs the pivot, its column of the diagonal tile and row p of every tile of the
-            // block row, all of them shaped by step p-1.  One wave per SIMD has nothing to hide the
-            // cross-lane latency behind but its own work, so step p updates first what step p+1
-            // fetches (the diagonal tile, and register (p+1)/4 of the other tiles), issues those
-            // fetches, and applies the other three quarters of its update while they travel.
-            d4 &a = G.acc[tri_index(K, K, NV)];
-            double inv, colv[4], rows[NV + 1];
-            auto fetch = [&](int p, double &inv_o, double (&colv_o)[4], double (&rows_o)[NV + 1]) {
-                const int gp = p & 3, rp = p >> 2;  // row p: lane group gp, register rp
-                const double d = read_lane(a[rp], 16 * gp + p);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * r + 3 > p) colv_o[r] = row_lane_d(a[r], p);  // A[g + 4r][p]
-#pragma unroll
-                for (int j = K; j < NV; ++j)
-                    rows_o[j] = shfl_d(G.acc[tri_index(K, j, NV)][rp], 16 * gp + q);
-                rows_o[NV] = shfl_d(rt[rp], 16 * gp + q);
-                inv_o = 1.0 / d;
-            };
-            fetch(0, inv, colv, rows);
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int gp = p & 3, rp = p >> 2;
-                const int rn = (p + 1) >> 2;  // the register the next step's row lives in
-                double m[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)  // rows at or above the pivot keep a zero
-                    m[r] = (4 * r + 3 > p && g + 4 * r > p) ? -colv[r] * inv : 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * r + 3 > p) a[r] = fma(m[r], rows[K], a[r]);
-                if (p < 15 && 4 * rn + 3 > p) {
-#pragma unroll
-                    for (int j = K + 1; j < NV; ++j) {
-                        d4 &t = G.acc[tri_index(K, j, NV)];
-                        t[rn] = fma(m[rn], rows[j], t[rn]);
-                    }
-                    rt[rn] = fma(m[rn], rows[NV], rt[rn]);
-                }
-                double inv_n = 0.0, colv_n[4], rows_n[NV + 1];
-                __builtin_amdgcn_sched_barrier(0);
-                if (p < 15) fetch(p + 1, inv_n, colv_n, rows_n);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = K + 1; j < NV; ++j) {
-                    d4 &t = G.acc[tri_index(K, j, NV)];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * r + 3 > p && !(p < 15 && r == rn)) t[r] = fma(m[r], rows[j], t[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * r + 3 > p && !(p < 15 && r == rn)) rt[r] = fma(m[r], rows[NV], rt[r]);
-                dv[rp] = (g == gp) ? inv : dv[rp];
-                __builtin_amdgcn_sched_barrier(0);
-                if (p < 15) {
-                    inv = inv_n;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) colv[r] = colv_n[r];
-#pragma unroll
-                    for (int j = K; j <= NV; ++j) rows[j] = rows_n[j];
-                }
-            }
+        if constexpr (NV >= F64_PIVOT4_MIN_NV) {
+            // Four pivots at a time, the row operations on the matrix cores.  Rows 4b .. 4b+3 of
+            // the block row (register b of lane group 0..3) are, as they stand, the B operand of
+            // v_mfma_f64_16x16x4 (lane (g,q): row 4b+g, column q), so T += W R with a 16 x 4
+            // matrix W of multipliers in the A operand (lane (g,q): W[q][g]) applies four
+            // elimination steps to a tile in one instruction and without moving a row between
+            // lanes.  With A11 = L D L^T the 4 x 4 pivot block, W is
+            //   rows below it     -A21 inv(A11): row q solves A11 x = -(column q of the four pivot
+            //                     rows), which by symmetry are A21's entries, via L and D
+            //   rows 4b .. 4b+3   inv(L) - I (what the four steps do to the pivot rows themselves)
+            //   rows above        0.
+            // Every lane factors A11 for itself (ten values fetched from its row of 16 by DPP) and
+            // solves for its own q; the only traffic between lane groups is the gather of the
+            // diagonal tile's four pivot-row values per lane (permlane swaps), none through LDS.
+            pivot4<0>(G, g, q, rt, dv, bad);
+            pivot4<1>(G, g, q, rt, dv, bad);
+            pivot4<2>(G, g, q, rt, dv, bad);
+            pivot4<3>(G, g, q, rt, dv, bad);
         } else {
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
@@ -1677,6 +1729,11 @@ struct PivotBlockD {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) bad |= (dv[r] > 0.0 && dv[r] < (double)INFINITY) ? 0 : 1;
+#ifdef ALSMI_PHASE_CLOCK
+        asm volatile("" ::"v"(rt[0]), "v"(dv[0]), "v"(bad));
+#endif
+        PHASE_T(tc1);
+        PHASE_ADD(pc, 4, tc0, tc1);
         d4 dz, zr, rs;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1688,10 +1745,27 @@ struct PivotBlockD {
 #pragma unroll
         for (int i = K + 1; i < NV; ++i) {
             const d4 zi = G.acc[tri_index(K, i, NV)];
+            // two tiles at a time, their instructions alternating: four in a row on one
+            // accumulator each wait for the one before
 #pragma unroll
-            for (int j = i; j < NV; ++j)
-                G.acc[tri_index(i, j, NV)] = mfma_xty_d(zi, -dv * G.acc[tri_index(K, j, NV)],
-                                                        G.acc[tri_index(i, j, NV)]);
+            for (int j = i; j < NV; j += 2) {
+                if (j + 1 < NV) {
+                    const d4 ya = -dv * G.acc[tri_index(K, j, NV)];
+                    const d4 yb = -dv * G.acc[tri_index(K, j + 1, NV)];
+                    d4 &ca = G.acc[tri_index(i, j, NV)];
+                    d4 &cb = G.acc[tri_index(i, j + 1, NV)];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        ca = __builtin_amdgcn_mfma_f64_16x16x4f64(zi[s], ya[s], ca, 0, 0, 0);
+                        cb = __builtin_amdgcn_mfma_f64_16x16x4f64(zi[s], yb[s], cb, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    G.acc[tri_index(i, j, NV)] = mfma_xty_d(zi, -dv * G.acc[tri_index(K, j, NV)],
+                                                            G.acc[tri_index(i, j, NV)]);
+                }
+            }
             double part = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
@@ -1703,13 +1777,18 @@ struct PivotBlockD {
             stash[((K * 8) + r) * WAVE + lane] = rs[r];
             stash[((K * 8) + 4 + r) * WAVE + lane] = zr[r];
         }
-        PivotBlockD<NV, K + 1>::run(G, lane, y, bad, stash);
+#ifdef ALSMI_PHASE_CLOCK
+        asm volatile("" ::"v"(y[NV - 1]), "v"(G.acc[Gram<double, NV>::NTRI - 1][0]));
+#endif
+        PHASE_T(tc2);
+        PHASE_ADD(pc, 5, tc1, tc2);
+        PivotBlockD<NV, K + 1>::run(G, lane, y, bad, stash, pc);
     }
 };
 template <int NV>
 struct PivotBlockD<NV, NV> {
     static __device__ __forceinline__ void run(Gram<double, NV> &, int, double (&)[NV], int &,
-                                               double *) {}
+                                               double *, long long *) {}
 };
 
 template <int NV, int K>
@@ -1742,16 +1821,29 @@ struct BackBlockD {
 // component of dimension q*NV + k.  False when a pivot is not positive or the result not finite.
 template <int NV>
 __device__ __forceinline__ bool block_solve_d(Gram<double, NV> &G, int lane, int rank, double ridge,
-                                              double (&xc)[NV], double *stash) {
+                                              double (&xc)[NV], double *stash,
+                                              long long *pc = nullptr) {
     asm volatile("" : "+v"(lane));
+    PHASE_T(ta);
     add_ridge<double, NV>(G, lane, rank, ridge);
     double y[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) y[e] = col_allreduce_d(G.b[e]);
     int bad = 0;
-    PivotBlockD<NV, 0>::run(G, lane, y, bad, stash);
+#ifdef ALSMI_PHASE_CLOCK
+    asm volatile("" ::"v"(y[NV - 1]));
+#endif
+    PHASE_T(tb);
+    PHASE_ADD(pc, 3, ta, tb);
+    PivotBlockD<NV, 0>::run(G, lane, y, bad, stash, pc);
+    PHASE_T(td);
     double chk = 0.0;
     BackBlockD<NV, NV - 1>::run(G, xc, chk, stash, lane);
+#ifdef ALSMI_PHASE_CLOCK
+    asm volatile("" ::"v"(xc[0]), "v"(chk));
+#endif
+    PHASE_T(te);
+    PHASE_ADD(pc, 6, td, te);
     return !__any(bad != 0 || !(chk < (double)INFINITY));
 }
 
@@ -2010,7 +2102,11 @@ __global__ __launch_bounds__((WPB * 64), (NV == 4 && !DUMP ? (sizeof(T) == 4 ? S
             if (p.solve_prio & 1) __builtin_amdgcn_s_setprio(1);
             const bool ok = block_solve_d<NV>(G, lane, p.rank, ridge, xs,
                                               reinterpret_cast<double *>(Asm) +
-                                                  WaveLds<T, KP, DUMP>::STASH_AT);
+                                                  WaveLds<T, KP, DUMP>::STASH_AT,
+                                              pc);
+#ifdef ALSMI_PHASE_CLOCK
+            pcs[7] += 1;
+#endif
             if (p.solve_prio & 1) __builtin_amdgcn_s_setprio(0);
             if (lane < 16) {
 #pragma unroll

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wave-clock cycles per phase of the fp32 row kernel (a library built with -DALSMI_PHASE_CLOCK,
-selected through ALSMI_LIB):  ALSMI_LIB=build/libalsmi_pc.so python tools/debug/phase_clock.py [config]
+selected through ALSMI_LIB):  ALSMI_LIB=build/libalsmi_pc.so python tools/debug/phase_clock.py [config [dtype]]
 Prints, per half-sweep side, the share of each phase in the waves' time and cycles per row."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,7 @@ cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else 'c2']
 device = dev.require_gpu()
 prob = synth.sharded_problem(20243, cfg['n'], cfg['m'], cfg['nnz'], 1, 0, device)
 eng = AlsEngine(prob['csr'], prob['csc'], (cfg['n'], cfg['m']), cfg['rank'], 0.1,
-                dtype=np.float32, total_nnz=int(prob['csr'][0][-1]))
+                dtype=np.dtype(sys.argv[2] if len(sys.argv) > 2 else 'float32'), total_nnz=int(prob['csr'][0][-1]))
 bench.init_factors(eng, cfg['rank'], device)
 lib = _lib.load()
 fn = lib.alsmi_debug_phase
