@@ -1742,34 +1742,62 @@ struct PivotBlockD {
             const double rtrue = last_col ? ((g + 4 * r == 15) ? 1.0 : 0.0) : rt[r];
             rs[r] = dv[r] * rtrue;
         }
+        if constexpr (NV >= F64_PIVOT4_MIN_NV) {
+            // (one wave per SIMD: registers for the scaled block row once per block, and the
+            // four dependent instructions of a tile spread over all tiles of the trailing part,
+            // so that none waits for its predecessor)
+            d4 ys[NV];
 #pragma unroll
-        for (int i = K + 1; i < NV; ++i) {
-            const d4 zi = G.acc[tri_index(K, i, NV)];
-            // two tiles at a time, their instructions alternating: four in a row on one
-            // accumulator each wait for the one before
+            for (int j = K + 1; j < NV; ++j) ys[j] = -dv * G.acc[tri_index(K, j, NV)];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = i; j < NV; j += 2) {
-                if (j + 1 < NV) {
-                    const d4 ya = -dv * G.acc[tri_index(K, j, NV)];
-                    const d4 yb = -dv * G.acc[tri_index(K, j + 1, NV)];
-                    d4 &ca = G.acc[tri_index(i, j, NV)];
-                    d4 &cb = G.acc[tri_index(i, j + 1, NV)];
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        ca = __builtin_amdgcn_mfma_f64_16x16x4f64(zi[s], ya[s], ca, 0, 0, 0);
-                        cb = __builtin_amdgcn_mfma_f64_16x16x4f64(zi[s], yb[s], cb, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                } else {
-                    G.acc[tri_index(i, j, NV)] = mfma_xty_d(zi, -dv * G.acc[tri_index(K, j, NV)],
-                                                            G.acc[tri_index(i, j, NV)]);
-                }
+                for (int i = K + 1; i < NV; ++i)
+#pragma unroll
+                    for (int j = i; j < NV; ++j)
+                        G.acc[tri_index(i, j, NV)] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                            G.acc[tri_index(K, i, NV)][s], ys[j][s], G.acc[tri_index(i, j, NV)], 0,
+                            0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = K + 1; i < NV; ++i) {
+                const d4 zi = G.acc[tri_index(K, i, NV)];
+                double part = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
+                y[i] -= col_allreduce_d(part);
             }
-            double part = 0.0;
+        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
-            y[i] -= col_allreduce_d(part);
+            for (int i = K + 1; i < NV; ++i) {
+                const d4 zi = G.acc[tri_index(K, i, NV)];
+                // two tiles at a time, their instructions alternating: four in a row on one
+                // accumulator each wait for the one before
+#pragma unroll
+                for (int j = i; j < NV; j += 2) {
+                    if (j + 1 < NV) {
+                        const d4 ya = -dv * G.acc[tri_index(K, j, NV)];
+                        const d4 yb = -dv * G.acc[tri_index(K, j + 1, NV)];
+                        d4 &ca = G.acc[tri_index(i, j, NV)];
+                        d4 &cb = G.acc[tri_index(i, j + 1, NV)];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            ca = __builtin_amdgcn_mfma_f64_16x16x4f64(zi[s], ya[s], ca, 0, 0, 0);
+                            cb = __builtin_amdgcn_mfma_f64_16x16x4f64(zi[s], yb[s], cb, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        G.acc[tri_index(i, j, NV)] = mfma_xty_d(zi, -dv * G.acc[tri_index(K, j, NV)],
+                                                                G.acc[tri_index(i, j, NV)]);
+                    }
+                }
+                double part = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part += zi[r] * dz[r];
+                y[i] -= col_allreduce_d(part);
+            }
         }
         // the block's back-substitution data waits in LDS
 #pragma unroll
