@@ -339,29 +339,31 @@ def test_dimc_config5_slice_properties():
     np.testing.assert_allclose(full, d.reconstruction_err_, rtol=1e-9)
 
 
-@pytest.mark.parametrize('rank', [64, 128])
-def test_half_sweeps_are_bit_reproducible_at_full_size(problem, rank):
+@pytest.mark.parametrize('rank,dtype', [(64, 'float32'), (128, 'float32'), (128, 'float64')])
+def test_half_sweeps_are_bit_reproducible_at_full_size(problem, rank, dtype):
     """Two runs of both half-sweeps (plain and error-summing kernels) over the whole
     138 493 x 26 744 / 20 M-entry matrix give bit-identical factors and error sums: 330 000
-    row solves per run, enough to see an event of one row in 10^5."""
+    row solves per run, enough to see an event of one row in 10^5.  (fp64 at rank 128: the kernel
+    whose matrix instructions are partly inline assembly with their own wait states.)"""
     torch, P = problem['torch'], problem['prob']
     from alsmi import device as dev
     device = problem['device']
     kp = dev.padded_rank(rank)
+    td = torch.float64 if dtype == 'float64' else torch.float32
     g = torch.Generator(device=device)
     g.manual_seed(1)
     for tri, n_rows, n_cols in ((P['csr'], N_USERS, N_ITEMS), (P['csc'], N_ITEMS, N_USERS)):
-        side = dev.SparseSide(tri[0], tri[1], tri[2], n_rows, n_cols, 'float32', device)
+        side = dev.SparseSide(tri[0], tri[1], tri[2], n_rows, n_cols, dtype, device)
         plan = dev.SweepPlan(side, rank)
-        src = torch.zeros((n_cols, kp), device=device)
-        src[:, :rank] = torch.rand((n_cols, rank), generator=g, device=device)
-        cur = torch.zeros((n_rows, kp), device=device)
-        cur[:, :rank] = torch.rand((n_rows, rank), generator=g, device=device)
+        src = torch.zeros((n_cols, kp), device=device, dtype=td)
+        src[:, :rank] = torch.rand((n_cols, rank), generator=g, device=device, dtype=td)
+        cur = torch.zeros((n_rows, kp), device=device, dtype=td)
+        cur[:, :rank] = torch.rand((n_rows, rank), generator=g, device=device, dtype=td)
         outs = []
         for _ in range(2):
-            a = torch.zeros((n_rows, kp), device=device)
+            a = torch.zeros((n_rows, kp), device=device, dtype=td)
             plan.half_sweep(src, a, 0.1)
-            b = torch.zeros((n_rows, kp), device=device)
+            b = torch.zeros((n_rows, kp), device=device, dtype=td)
             sse = float(plan.half_sweep_err(src, cur, b, 0.1).cpu()[0])
             outs.append((a, b, sse))
         assert torch.equal(outs[0][0], outs[1][0])

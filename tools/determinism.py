@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Run the same half-sweep several times and report whether the outputs are bit-identical."""
+"""Run the same half-sweep several times and report whether the outputs are bit-identical.
+
+    python tools/determinism.py [float32|float64 [rank ...]]
+"""
 import os
 import sys
 
@@ -12,25 +15,27 @@ for p in (ROOT, os.path.join(ROOT, 'recommendation-models_amd'), os.path.join(RO
 from alsmi import device as dev, synth  # noqa: E402
 
 device = dev.require_gpu()
-for (n, m, nnz, rank) in ((138493, 26744, 20000000, 64), (138493, 26744, 20000000, 10),
-                          (138493, 26744, 20000000, 32), (138493, 26744, 20000000, 128)):
+dtype = sys.argv[1] if len(sys.argv) > 1 else 'float32'
+td = torch.float64 if dtype == 'float64' else torch.float32
+ranks = [int(a) for a in sys.argv[2:]] or [64, 10, 32, 128]
+for (n, m, nnz, rank) in [(138493, 26744, 20000000, r) for r in ranks]:
     prob = synth.sharded_problem(20242, n, m, nnz, 1, 0, device)
     for name, tri, ncols in (('user', prob['csr'], m), ('item', prob['csc'], n)):
-        side = dev.SparseSide(tri[0], tri[1], tri[2], len(tri[0]) - 1, ncols, 'float32', device)
+        side = dev.SparseSide(tri[0], tri[1], tri[2], len(tri[0]) - 1, ncols, dtype, device)
         plan = dev.SweepPlan(side, rank)
         kp = dev.padded_rank(rank)
         g = torch.Generator(device=device); g.manual_seed(1)
-        src = torch.zeros((ncols, kp), device=device)
-        src[:, :rank] = torch.rand((ncols, rank), generator=g, device=device)
+        src = torch.zeros((ncols, kp), device=device, dtype=td)
+        src[:, :rank] = torch.rand((ncols, rank), generator=g, device=device, dtype=td)
         outs = []
         for rep in range(8):
-            dst = torch.zeros((side.n_rows, kp), device=device)
+            dst = torch.zeros((side.n_rows, kp), device=device, dtype=td)
             plan.half_sweep(src, dst, 0.1)
             outs.append(dst)
         cur = outs[0].clone()
         errs = []
         for rep in range(3):
-            dst = torch.zeros((side.n_rows, kp), device=device)
+            dst = torch.zeros((side.n_rows, kp), device=device, dtype=td)
             errs.append(float(plan.half_sweep_err(src, cur, dst, 0.1).cpu()[0]))
             outs.append(dst)
         same = [bool(torch.equal(outs[0], o)) for o in outs[1:8]]
