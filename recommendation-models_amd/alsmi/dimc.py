@@ -91,7 +91,10 @@ class DirtyIMC(BaseEstimator):
         xzy = prob.predict_samples(self.imc.Z)
         self.als.fit((users, items), r_ - xzy, shape=shape)
         self.als.shape_ = tuple(int(v) for v in shape)
-        self.reconstruction_err_ = self.score(X, y)
+        # score(X, y) (src/dimc.py:160) from the parts at hand: the same samples' x^T Z y are in
+        # xzy already, so the IMC problem is not grouped and uploaded a second time
+        uv = self.als._pair_predictions(users, items)
+        self.reconstruction_err_ = -root_mean_squared_error(r_, uv + xzy)
         return self.imc.Z, self.als.user_feats, self.als.item_feats
 
     def predict(self, X):

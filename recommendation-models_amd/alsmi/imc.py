@@ -67,10 +67,16 @@ class ImcProblem(object):
         self.n_samples = int(users.size)
         self.ratings_host = ratings  # all samples, caller order (score needs every rank's)
         # group the samples by user; `order` maps grouped position -> caller position
-        self.order = np.argsort(users, kind='stable')
         indptr = np.zeros(self.n_users + 1, dtype=np.int64)
         np.cumsum(np.bincount(users, minlength=self.n_users), out=indptr[1:])
-        items_g, ratings_g = items[self.order].astype(np.int32), ratings[self.order]
+        if users.size < 2 or bool(np.all(users[1:] >= users[:-1])):
+            # already grouped (samples listed user by user, e.g. taken from a CSR matrix):
+            # no sort and no reordering copies
+            self.order = None
+            items_g, ratings_g = items.astype(np.int32), ratings
+        else:
+            self.order = np.argsort(users, kind='stable')
+            items_g, ratings_g = items[self.order].astype(np.int32), ratings[self.order]
         # this rank's users [ulo, uhi) and their samples [slo, shi) of the grouped order
         self.ulo, self.uhi, self.slo, self.shi = 0, self.n_users, 0, self.n_samples
         if shard is not None:
