@@ -452,8 +452,13 @@ class IMC(BaseEstimator):
         if issparse(y):
             y = y.tocsr()
             rows, cols = y.nonzero()
-            return ImcProblem(x, y_, rows, cols, np.asarray(y[rows, cols]).ravel(),
-                              group=default_group())
+            if y.has_canonical_format:
+                # sorted, no duplicates: the values at (rows, cols) are the stored non-zero
+                # values in storage order; no lookup per entry
+                vals = y.data[y.data != 0]
+            else:
+                vals = np.asarray(y[rows, cols]).ravel()
+            return ImcProblem(x, y_, rows, cols, vals, group=default_group())
         return problem_from_samples(x, y_, y)
 
     def _fit_on(self, prob, Z=None):
