@@ -15,6 +15,7 @@ ap.add_argument('--k', type=int, default=10)
 ap.add_argument('--rank', type=int, default=64)
 ap.add_argument('--users', type=int, default=138493)
 ap.add_argument('--items', type=int, default=26744)
+ap.add_argument('--ws-mb', type=int, default=0, help='score workspace per batch in MiB (0: the default)')
 a = ap.parse_args()
 d = dev.require_gpu()
 td = torch.float64 if a.dtype == 'float64' else torch.float32
@@ -25,7 +26,8 @@ V = torch.zeros((a.items, kp), dtype=td, device=d); V[:, :a.rank] = torch.rand((
 users = torch.arange(a.users, dtype=torch.int32, device=d)
 dev.topk_items(a.rank, users[:1000], U, V, a.k); torch.cuda.synchronize()
 t0 = time.perf_counter()
-items, scores = dev.topk_items(a.rank, users, U, V, a.k)
+kw = dict(max_workspace_bytes=a.ws_mb << 20) if a.ws_mb else {}
+items, scores = dev.topk_items(a.rank, users, U, V, a.k, **kw)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 s = a.dtype == 'float64' and 8 or 4
