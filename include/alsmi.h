@@ -145,7 +145,7 @@ int alsmi_sddmm_noalloc(int dtype, int rank, int64_t n_pairs, const int32_t *use
  *
  * For every p < n_sel: the k items i with the largest <user_factors[users[p]],
  * item_factors[i]>, best first, ties broken by the smaller item id; items_out [n_sel x k]
- * int32, scores_out [n_sel x k] of dtype.  1 <= k <= min(1024, n_items), n_items <= 2^24.
+ * int32, scores_out [n_sel x k] of dtype.  1 <= k <= min(1024, n_items), n_items <= 16 776 960.
  * workspace: at least
  * alsmi_topk_workspace_bytes(dtype, n_sel, n_items) bytes (the dense n_sel x n_items score
  * block: batch the users accordingly).  Deterministic. */
