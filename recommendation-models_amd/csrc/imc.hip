@@ -22,6 +22,16 @@ namespace alsmi {
 
 constexpr int IMC_MAX_Q = 256;
 constexpr int IMC_KSPLIT = 128;
+// Slices of the reduction over users in out = X^T W: 128 at 128 x 256 attributes (16 output
+// tile blocks per slice); more where the output is smaller, so that the launch still has some
+// 2 000 waves (at 32 x 64 attributes one tile block per slice left 128 waves on 1 024 SIMDs) —
+// the partial results take the same memory either way.
+static int imc_ksplit_max(int p, int q) {
+    int64_t s = (int64_t)IMC_KSPLIT * (128 * 256) / ((int64_t)p * q);
+    if (s < IMC_KSPLIT) s = IMC_KSPLIT;
+    if (s > 2048) s = 2048;
+    return (int)s;
+}
 
 // ---- C[M x N] = op(A) B on v_mfma_*_16x16x4, a block of TM x TN 16x16 tiles per wave ----------
 // TRANS_A = false: A is [M x K] row-major (lda).  TRANS_A = true: A is [K x M] row-major.
@@ -141,16 +151,30 @@ static void launch_gemm(int M, int N, int NB, int64_t K, const T *A, int64_t lda
 #undef ALSMI_GEMM
 }
 
-// out[i] = sum_z partials[z * count + i], fixed order.
+// out[i] = sum_z partials[z * count + i] in a fixed order: a workgroup takes 64 consecutive
+// outputs, its four waves a quarter of the slices each (four running sums per thread, so that
+// four loads are in flight), and the sixteen part sums of an output are added in index order.
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const T *__restrict__ partials,
                                                               int nz, int64_t count,
                                                               T *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    T s = T(0);
-    for (int z = 0; z < nz; ++z) s += partials[(int64_t)z * count + i];
-    out[i] = s;
+    __shared__ T part[4][64];
+    const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
+    const int per = (nz + 3) / 4;
+    const int z0 = w * per, z1 = z0 + per < nz ? z0 + per : nz;
+    T s[4] = {T(0), T(0), T(0), T(0)};
+    if (i < count) {
+        int z = z0;
+        for (; z + 4 <= z1; z += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += partials[(int64_t)(z + u) * count + i];
+        }
+        for (int u = 0; z < z1; ++z, ++u) s[u] += partials[(int64_t)z * count + i];
+    }
+    part[w][e] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (w == 0 && i < count) out[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
 // ---- fused SDDMM + SpMM over the stored entries ------------------------------------------------
@@ -164,10 +188,20 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const T *__restric
 // ratings (the item-major pass of the rank-constrained form) no longer serialises on one wave —
 // and every sum is formed in a fixed order.  mode 0: w = d - r and the squared error is
 // accumulated; mode 1: w = d.  W must be zero on entry (users without entries keep that).
+// Entries per chunk: 2048 where users have many entries; fewer where they have few, because a
+// wave walks the users of its chunk one after the other (each a chain of dependent loads) and
+// only more waves hide that: with one entry per user — the reference's own per-sample form,
+// where every sample is its own user — 2048-entry chunks left one wave per SIMD waiting on
+// memory (3.5 ms per evaluation at 2 M samples; 128-entry chunks: see the design notes).
 constexpr int IMC_CHUNK = 2048;
+static int imc_chunk(int64_t n_users, int64_t n_samples) {
+    const int64_t mean = n_samples / (n_users > 0 ? n_users : 1);
+    return mean < 8 ? 128 : (mean < 64 ? 512 : IMC_CHUNK);
+}
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void imc_rows_kernel(int mode, int64_t n_users, int64_t n_chunks,
+                                                       int chunk,
                                                        const int64_t *__restrict__ indptr,
                                                        const int32_t *__restrict__ items,
                                                        const T *__restrict__ ratings,
@@ -184,8 +218,8 @@ __global__ __launch_bounds__(256) void imc_rows_kernel(int mode, int64_t n_users
     const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const int64_t nnz = indptr[n_users];
-    const int64_t c0 = c * IMC_CHUNK;
-    const int64_t c1 = c0 + IMC_CHUNK < nnz ? c0 + IMC_CHUNK : nnz;
+    const int64_t c0 = c * chunk;
+    const int64_t c1 = c0 + chunk < nnz ? c0 + chunk : nnz;
     // the user of entry c0: the last u with indptr[u] <= c0
     int64_t lo = 0, hi = n_users;
     while (hi - lo > 1) {
@@ -266,6 +300,111 @@ __global__ __launch_bounds__(256) void imc_rows_kernel(int mode, int64_t n_users
     if (lane == 0) partials[c] = sse;
 }
 
+// The same pass for users with few entries (chunks of at most 128 entries): FOUR users at a
+// time, one per lane group, each walking its own entries.  With one wave per user the wave's 64
+// lanes served one or two entries per step and the three dependent loads of a user (extent,
+// item index, item row) were waited for one user after the other.  Each user's sums are formed
+// in entry order by its own 16 lanes; the border rules are those of imc_rows_kernel.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void imc_rows4_kernel(int mode, int64_t n_users, int64_t n_chunks,
+                                                        int chunk,
+                                                        const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ items,
+                                                        const T *__restrict__ ratings,
+                                                        const T *__restrict__ Atab,
+                                                        const T *__restrict__ Y,
+                                                        T *__restrict__ W,
+                                                        T *__restrict__ pred_out,
+                                                        T *__restrict__ border,
+                                                        int64_t *__restrict__ border_user,
+                                                        double *__restrict__ partials) {
+    constexpr int LD = NV * 16;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int64_t nnz = indptr[n_users];
+    const int64_t c0 = c * chunk;
+    const int64_t c1 = c0 + chunk < nnz ? c0 + chunk : nnz;
+    int64_t lo = 0, hi = n_users;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= c0) lo = mid; else hi = mid;
+    }
+    double sse = 0.0;
+    if (lane == 0) {
+        border_user[2 * c] = -1;
+        border_user[2 * c + 1] = -1;
+    }
+    for (int64_t ub = lo; ub < n_users; ub += 4) {
+        if (indptr[ub] >= c1) break;  // (the same for the whole wave)
+        const int64_t u = ub + g;
+        int64_t rb = 0, re = 0;
+        if (u < n_users) {
+            rb = indptr[u];
+            re = indptr[u + 1];
+        }
+        const int64_t beg = rb > c0 ? rb : c0, end = re < c1 ? re : c1;
+        const int cnt = end > beg ? (int)(end - beg) : 0;  // this lane group's entries
+        int most = cnt;
+        most = max(most, __shfl_xor(most, 16));
+        most = max(most, __shfl_xor(most, 32));
+        T a[NV], wacc[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            a[e] = T(0);
+            wacc[e] = T(0);
+        }
+        if (cnt > 0) load_vec<T, NV>(a, Atab + u * LD + q * NV);
+        for (int t = 0; t < most; ++t) {
+            const bool on = t < cnt;
+            int it = 0;
+            T rr = T(0);
+            if (on) {
+                it = items[beg + t];
+                if (mode == 0) rr = ratings[beg + t];
+            }
+            T y[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) y[e] = T(0);
+            if (on) load_vec<T, NV>(y, Y + (int64_t)it * LD + q * NV);
+            T d = T(0);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) d += a[e] * y[e];
+            d += __shfl_xor(d, 1);
+            d += __shfl_xor(d, 2);
+            d += __shfl_xor(d, 4);
+            d += __shfl_xor(d, 8);
+            T w = T(0);
+            if (on) {
+                w = mode == 0 ? d - rr : d;
+                if (q == 0) {
+                    if (pred_out) pred_out[beg + t] = d;
+                    if (mode == 0) {
+                        const double err = (double)rr - (double)d;
+                        sse += err * err;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NV; ++e) wacc[e] += w * y[e];
+        }
+        if (cnt > 0) {
+            const bool head = rb < c0, tail = re > c1;
+            T *dst = W + u * LD;
+            if (head || tail) {
+                const int slot = head ? 0 : 1;
+                dst = border + (2 * c + slot) * LD;
+                if (q == 0) border_user[2 * c + slot] = u;
+            }
+#pragma unroll
+            for (int e = 0; e < NV; ++e) dst[q * NV + e] = wacc[e];
+        }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) partials[c] = sse;
+}
+
 // Adds the border parts of every user that a chunk border cut, in chunk order: the wave of the
 // chunk where the user's first entry lies (its tail slot, or its head slot for chunk 0 never —
 // a head is by definition not the first part) walks the following chunks' head slots while they
@@ -315,17 +454,19 @@ static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 struct ImcWorkspace {
     size_t a_off, w_off, part_off, sse_off, border_off, border_user_off, total;
     int64_t n_chunks;
+    int chunk;
 };
 
 static ImcWorkspace imc_layout(size_t esz, int64_t n_users, int64_t n_samples, int p, int q) {
     ImcWorkspace ws;
     const size_t table = align256((size_t)n_users * imc_ld(q) * esz);
-    ws.n_chunks = (n_samples + IMC_CHUNK - 1) / IMC_CHUNK;
+    ws.chunk = imc_chunk(n_users, n_samples);
+    ws.n_chunks = (n_samples + ws.chunk - 1) / ws.chunk;
     if (ws.n_chunks < 1) ws.n_chunks = 1;
     ws.a_off = 0;
     ws.w_off = table;
     ws.part_off = 2 * table;
-    ws.sse_off = ws.part_off + align256((size_t)IMC_KSPLIT * p * q * esz);
+    ws.sse_off = ws.part_off + align256((size_t)imc_ksplit_max(p, q) * p * q * esz);
     ws.border_off = ws.sse_off + align256((size_t)ws.n_chunks * sizeof(double));
     ws.border_user_off = ws.border_off + align256((size_t)2 * ws.n_chunks * imc_ld(q) * esz);
     ws.total = ws.border_user_off + align256((size_t)2 * ws.n_chunks * sizeof(int64_t));
@@ -333,12 +474,16 @@ static ImcWorkspace imc_layout(size_t esz, int64_t n_users, int64_t n_samples, i
 }
 
 template <typename T, int NV>
-static void launch_rows(int64_t n_chunks, int mode, int64_t n_users, const int64_t *indptr,
+static void launch_rows(int64_t n_chunks, int chunk, int mode, int64_t n_users,
+                        const int64_t *indptr,
                         const int32_t *items, const void *ratings, const T *Atab, const void *Y,
                         T *Wtab, void *pred_out, T *border, int64_t *border_user,
                         double *sse_part, hipStream_t st) {
-    hipLaunchKernelGGL((imc_rows_kernel<T, NV>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0,
-                       st, mode, n_users, n_chunks, indptr, items, static_cast<const T *>(ratings),
+    // users with few entries (short chunks): four users per wave
+    auto kern = chunk <= 128 ? imc_rows4_kernel<T, NV> : imc_rows_kernel<T, NV>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0,
+                       st, mode, n_users, n_chunks, chunk, indptr, items,
+                       static_cast<const T *>(ratings),
                        Atab, static_cast<const T *>(Y), Wtab, static_cast<T *>(pred_out), border,
                        border_user, sse_part);
 }
@@ -371,7 +516,8 @@ static int run_imc_eval(int mode, int64_t n_users, int64_t n_samples, int p, int
         switch (ld / 16) {
 #define ALSMI_ROWS(NV)                                                                          \
     case NV:                                                                                    \
-        launch_rows<T, NV>(nc, mode, n_users, indptr, items, ratings, Atab, Y, Wtab, pred_out,  \
+        launch_rows<T, NV>(nc, ws.chunk, mode, n_users, indptr, items, ratings, Atab, Y, Wtab,  \
+                           pred_out,                                                            \
                            border, border_user, sse_part, st);                                  \
         break;
             ALSMI_ROWS(1) ALSMI_ROWS(2) ALSMI_ROWS(4) ALSMI_ROWS(8) ALSMI_ROWS(16)
@@ -395,13 +541,13 @@ static int run_imc_eval(int mode, int64_t n_users, int64_t n_samples, int p, int
     // are added in slice order (reproducible for a given n_users)
     if (out) {
         int ksplit = (int)((n_users + 255) / 256);
-        if (ksplit > IMC_KSPLIT) ksplit = IMC_KSPLIT;
+        if (ksplit > imc_ksplit_max(p, q)) ksplit = imc_ksplit_max(p, q);
         if (ksplit < 1) ksplit = 1;
         const int64_t count = (int64_t)p * q;
         launch_gemm<T, true>(p, q, q, n_users, static_cast<const T *>(X), (int64_t)p, Wtab,
                              (int64_t)ld, part, (int64_t)q, ksplit, count, st);
         ALSMI_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((count + 255) / 256)),
+        hipLaunchKernelGGL((reduce_partials_kernel<T>), dim3((unsigned)((count + 63) / 64)),
                            dim3(256), 0, st, part, ksplit, count, static_cast<T *>(out));
         ALSMI_HIP_CHECK(hipGetLastError());
     }
