@@ -500,9 +500,15 @@ class IMC(BaseEstimator):
         x_arr, y_arr = np.asarray(x), np.asarray(y_)
         x2, y2 = np.atleast_2d(x_arr), np.atleast_2d(y_arr)
         n, m = x2.shape[0], y2.shape[0]
-        rows = np.repeat(np.arange(n), m)
-        cols = np.tile(np.arange(m), n)
-        prob = ImcProblem(x2, y2, rows, cols, np.zeros(n * m))
+        # every (row of X, row of Y) pair as one sample, user by user; the n*m index entries are
+        # generated on the device instead of being built on the host, grouped and uploaded
+        import torch
+        device = dev.require_gpu()
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+        indptr = torch.arange(n + 1, dtype=torch.int64, device=device) * m
+        cols = torch.arange(m, dtype=torch.int32, device=device).repeat(n)
+        zeros = torch.zeros(n * m, dtype=torch.float64, device=device)
+        prob = ImcProblem.from_device_csr(indptr, cols, zeros, to(x2), to(y2))
         pred = prob.predict_samples(self.Z).reshape(n, m)
         if x_arr.ndim == 1 and y_arr.ndim == 1:
             return pred[0, 0]
