@@ -65,6 +65,35 @@ def test_evaluations_match_reference_vectors(gpu, golden, form):
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize('dtype,tol', [('float64', 1e-10), ('float32', 2e-4)])
+def test_users_with_few_entries_and_chunk_borders(gpu, dtype, tol):
+    """Mean entries per user below 8: the short-chunk path (four users per wave, 128-entry
+    chunks).  2 000 users with 0-5 entries and one with 700, which spans several chunks, so
+    head, tail and whole-chunk border parts all occur; sample order shuffled."""
+    from alsmi.imc import ImcProblem
+    from oracle import imc_oracle as io
+    rng = np.random.default_rng(11)
+    n, m, p, q = 2000, 900, 12, 40
+    deg = rng.integers(0, 6, n)
+    deg[777] = 700
+    users = np.repeat(np.arange(n), deg)
+    items = np.concatenate([rng.choice(m, size=d, replace=False) for d in deg])
+    perm = rng.permutation(users.size)
+    users, items = users[perm], items[perm]
+    vals = rng.standard_normal(users.size)
+    X = rng.standard_normal((n, p)) / np.sqrt(p)
+    Y = rng.standard_normal((m, q)) / np.sqrt(q)
+    Z, S = rng.standard_normal((p, q)), rng.standard_normal((p, q))
+    prob = ImcProblem(X, Y, users, items, vals, dtype=dtype)
+    if dtype == 'float32':
+        X, Y = X.astype(np.float32).astype(np.float64), Y.astype(np.float32).astype(np.float64)
+    rel = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max()
+    assert rel(prob.cost(Z, 0.3), io.cost_indexed(Z, X, Y, users, items, vals, 0.3)) <= tol
+    assert rel(prob.grad(Z, 0.3), io.grad_indexed(Z, X, Y, users, items, vals, 0.3)) <= tol
+    assert rel(prob.hessp(S, 0.3), io.hessp_indexed(S, X, Y, users, items, 0.3)) <= tol
+    assert rel(prob.predict_samples(Z), io.preds_indexed(Z, X, Y, users, items)) <= tol
+
+
 @pytest.mark.parametrize('p,q', [(3, 1), (17, 16), (5, 33), (130, 100), (40, 256)])
 def test_evaluations_match_oracle_shapes(gpu, p, q):
     """attribute widths around every padding boundary, empty users, one long user."""
