@@ -52,6 +52,36 @@ def test_topk_items_match_dense_ranking(dtype, rank, m, k):
             assert rest.max() <= scores[r, -1] + (1e-12 if dtype == 'float64' else 5e-5)
 
 
+@pytest.mark.parametrize('dtype,rank,n_sel,m,k', [('float32', 64, 300, 1007, 10),
+                                                   ('float64', 128, 150, 333, 33),
+                                                   ('float32', 5, 65, 17, 17)])
+def test_topk_many_users_partial_tiles(dtype, rank, n_sel, m, k):
+    """Several blocks of users (the last one partly filled) and an item count that is no multiple
+    of the 16-item tile: every reported score is the score of its item, best first, no item
+    twice, nothing outside the list beats its last entry."""
+    import torch
+    from alsmi import device as dev
+    device = dev.require_gpu()
+    rng = np.random.default_rng(rank * 7 + n_sel)
+    n = n_sel + 13
+    Ud = dev.factors_to_device(rng.standard_normal((rank, n)), dtype, device)
+    Vd = dev.factors_to_device(rng.standard_normal((rank, m)), dtype, device)
+    users = rng.permutation(n)[:n_sel].astype(np.int32)
+    items, scores = dev.topk_items(rank, torch.from_numpy(users).to(device), Ud, Vd, k)
+    items = items.cpu().numpy().astype(np.int64)
+    scores = scores.to(torch.float64).cpu().numpy()
+    Uq, Vq = dev.factors_to_host(Ud, rank), dev.factors_to_host(Vd, rank)
+    dense = Uq[:, users].T.dot(Vq)
+    tol = 1e-12 if dtype == 'float64' else 5e-5
+    np.testing.assert_allclose(np.take_along_axis(dense, items, axis=1), scores, rtol=tol, atol=tol)
+    assert (np.diff(scores, axis=1) <= 0).all()
+    assert all(np.unique(r).size == k for r in items)
+    for r in range(n_sel):
+        rest = np.delete(dense[r], items[r])
+        if rest.size:
+            assert rest.max() <= scores[r, -1] + 2 * tol
+
+
 def test_als_recommend(golden):
     from alsmi import ALS
     import scipy.sparse as sps
