@@ -92,8 +92,11 @@ class ImcProblem(object):
             Y_attrs, items_g = Y_attrs[uniq], inv.astype(np.int32)
         self.n_local_users = self.uhi - self.ulo
         self.n_local_samples = self.shi - self.slo
-        ypad = np.zeros((Y_attrs.shape[0], self.ld))
-        ypad[:, :self.q] = Y_attrs
+        if self.q == self.ld:
+            ypad = Y_attrs  # the row stride needs no padding: no second host copy of the table
+        else:
+            ypad = np.zeros((Y_attrs.shape[0], self.ld))
+            ypad[:, :self.q] = Y_attrs
         self._place(indptr, items_g, ratings_g, X_attrs, ypad)
 
     @classmethod
