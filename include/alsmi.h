@@ -201,7 +201,9 @@ int alsmi_csr_to_csc(int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
  * Calling mode 0 with M = 0 and negated ratings gives X^T diag(r) Y of
  * src/imc.py:157.  1 <= q <= 256.  n_samples = indptr[n_users] (the host needs it to size
  * the launch: the pass cuts the ENTRIES, not the users, into equal chunks, so its time does not
- * depend on how unevenly the entries are spread over the users; every sum has a fixed order). */
+ * depend on how unevenly the entries are spread over the users; every sum has a fixed order).
+ * The workspace layout depends on all of n_users, n_samples, p and q (chunk length and the
+ * number of partial results follow from them): size it with exactly the values of the call. */
 int alsmi_imc_padded_width(int q);
 size_t alsmi_imc_workspace_bytes(int dtype, int64_t n_users, int64_t n_samples, int p, int q);
 int alsmi_imc_eval(int dtype, int mode, int64_t n_users, int64_t n_samples, int p, int q,
