@@ -274,7 +274,14 @@ def main():
         torch.cuda.set_device(local)
         device = torch.device('cuda', local)
     group = None
-    if world > 1:
+    # ALSMI_FORCE_COLLECTIVES=1 with one rank: a one-rank group whose gathers and all-reduces
+    # are really issued (the multi-rank code path on RCCL with the one GPU at hand)
+    forced = world == 1 and os.environ.get('ALSMI_FORCE_COLLECTIVES', '0') not in ('', '0')
+    if forced:
+        os.environ.setdefault('MASTER_PORT', '29577')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if world > 1 or forced:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if dist_backend == 'nccl':
@@ -305,7 +312,7 @@ def main():
         return eng
 
     def barrier():
-        if world > 1:
+        if group is not None:
             import torch.distributed as dist
             dist.barrier()
         if cuda:
@@ -313,13 +320,19 @@ def main():
 
     fused = not args.separate_error
     engine = make_engine(args.dtype)
+    engine.time_gathers = engine.collective
     elapsed, t_user, t_item, t_sse, rmse = timed_sweeps(engine, args.steps, args.warmup, fused,
                                                         barrier, cuda)
-    if world > 1:
+    # time the compute stream spent waiting for row gathers, per half-sweep (this rank; the
+    # warm-up sweeps are in the sum as well, hence the division by all sweeps run)
+    exposed = engine.gather_exposed_ms() / (2.0 * (args.steps + args.warmup)) \
+        if engine.collective else None
+    if group is not None:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, exposed or 0.0], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.cpu()[0])
+        exposed = float(t.cpu()[1])
 
     # float64 companion (the reference's arithmetic, the 1e-10 parity mode) for the default
     # single-GPU run: same problem, same schedule, a few sweeps after the timed region
@@ -392,7 +405,15 @@ def main():
                            {'schedule': 'standalone pass after every sweep'}),
             'train_rmse': {'first': rmse[0] if rmse else None, 'last': rmse[-1] if rmse else None},
             'setup_s': {'generate': t_gen},
+            'backend': 'hip' if plug is None else 'stand-in ' + plug,
         }
+        if exposed is not None:
+            line['allgather_exposed_ms'] = exposed
+            line['allgather'] = ('all-gather-v of the updated rows as one broadcast per owning '
+                                 'rank, straight into the factor table, %d user / %d item slabs '
+                                 'per rank in flight beside the next slab\'s kernels; exposed = '
+                                 'mean time per half-sweep the compute stream waited for them '
+                                 '(max over ranks)' % (len(engine.plans_u), len(engine.plans_i)))
         if f64:
             line['f64'] = f64
         if world == 1 and args.cpu_frac > 0 and cuda:
@@ -403,7 +424,7 @@ def main():
                 line['cpu_baseline'] = {'value': None, 'unit': 'nnz/s', 'cores': threads,
                                         'kind': 'port', 'sample': 'failed: %r' % (exc,)}
         print(json.dumps(line))
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

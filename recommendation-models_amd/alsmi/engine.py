@@ -16,10 +16,19 @@ import torch
 from . import device as dev
 
 
+def force_collectives():
+    """ALSMI_FORCE_COLLECTIVES=1: a process group of ONE rank still goes through every
+    collective of the multi-rank path (the broadcasts of the row gathers, the all-reduces),
+    which lets a one-GPU machine run that path on RCCL."""
+    return os.environ.get('ALSMI_FORCE_COLLECTIVES', '0') not in ('', '0')
+
+
 def default_group():
-    """The world group when torch.distributed runs with more than one rank, else None."""
+    """The world group when torch.distributed runs with more than one rank (or with one rank
+    and the collectives forced on), else None."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size() > 1 or force_collectives()):
         return dist.group.WORLD
     return None
 
@@ -86,6 +95,10 @@ class AlsEngine(object):
             self.me = dist.get_rank(group)
         else:
             self.world, self.me = 1, 0
+        # whether the half-sweeps end in collectives: always with several ranks; with a group
+        # of one rank only on request (the calls are then in-place broadcasts to itself)
+        self.collective = group is not None and (self.world > 1 or force_collectives())
+        self.time_gathers, self._gather_stamps = False, []
         self.user_bounds = np.asarray([0, self.n] if user_bounds is None else user_bounds,
                                       dtype=np.int64)
         self.item_bounds = np.asarray([0, self.m] if item_bounds is None else item_bounds,
@@ -103,10 +116,10 @@ class AlsEngine(object):
         # rank 128).
         if user_slabs is None:
             user_slabs = int(os.environ.get('ALSMI_USER_SLABS', '0')) or \
-                (1 if self.world == 1 else 4)
+                (4 if self.collective else 1)
         if item_slabs is None:
             item_slabs = int(os.environ.get('ALSMI_ITEM_SLABS', '0')) or \
-                (1 if self.world == 1 else 2)
+                (2 if self.collective else 1)
         self.u_sub = split_by_nnz(self.csr.indptr_host, max(1, int(user_slabs)))
         self.i_sub = split_by_nnz(self.csc.indptr_host, max(1, int(item_slabs)))
         self.plans_u = [b.make_plan(self.csr, self.rank, chunk, int(lo), int(hi))
@@ -122,42 +135,29 @@ class AlsEngine(object):
         self.local_nnz = self.csr.nnz
         if total_nnz is None:
             total_nnz = self.local_nnz
-            if self.world > 1:
+            if self.collective:
                 import torch.distributed as dist
                 t = torch.tensor([float(self.local_nnz)], dtype=torch.float64,
                                  device=self.U.device)
                 dist.all_reduce(t, group=group)
                 total_nnz = int(t.cpu()[0])
         self.nnz = int(total_nnz)
-        # every rank's slab boundaries (global row ids), [world x slabs+1], and the staging
-        # buffers of the slab gathers (allocated once: nothing is allocated inside a sweep)
+        self._host_bounce = False
+        if self.collective:
+            import torch.distributed as dist
+            self._host_bounce = self.U.is_cuda and dist.get_backend(group) == 'gloo'
+        # every rank's slab boundaries (global row ids), [world x slabs+1]
         self.u_sub_all = self._exchange_bounds(self.u_sub + self.ulo)
         self.i_sub_all = self._exchange_bounds(self.i_sub + self.ilo)
-        self._stage_u = self._make_stages(self.u_sub_all, self.U)
-        self._stage_i = self._make_stages(self.i_sub_all, self.V)
 
     def _exchange_bounds(self, mine_np):
         mine = torch.from_numpy(np.ascontiguousarray(mine_np)).to(self.U.device)
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             every = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
             dist.all_gather_into_tensor(every, mine, group=self.group)
             return every.cpu().numpy().reshape(self.world, -1)
         return mine.cpu().numpy().reshape(1, -1)
-
-    def _make_stages(self, sub_all, table):
-        """Per slab: (send [width x ld], recv [world*width x ld]) with width = the longest
-        rank's slab; None on a single rank."""
-        if self.world == 1:
-            return None
-        out = []
-        for s in range(sub_all.shape[1] - 1):
-            width = int((sub_all[:, s + 1] - sub_all[:, s]).max())
-            out.append((torch.zeros((width, table.shape[1]), dtype=table.dtype,
-                                    device=table.device),
-                        torch.empty((self.world * width, table.shape[1]), dtype=table.dtype,
-                                    device=table.device)))
-        return out
 
     @classmethod
     def from_global(cls, indptr, indices, vals, shape, rank, alpha, dtype=np.float64,
@@ -198,63 +198,82 @@ class AlsEngine(object):
         return dev.factors_to_host(self.U, self.rank), dev.factors_to_host(self.V, self.rank)
 
     # ---- collectives --------------------------------------------------------
+    # The all-gather of updated factor rows is an all-gather-v done as one broadcast per
+    # owning rank, each straight from and into the rows of the factor table itself: the row
+    # ranges differ from rank to rank (they are balanced by stored entries), so nothing is
+    # padded, staged or copied afterwards, and the same calls serve RCCL on device tensors and
+    # gloo on host tensors.  (c10d's own all_gather of unequal tensors is the same group of
+    # broadcasts.)
+    def _bcast_rows(self, table, los, his, async_op):
+        """Rank r sends rows [los[r], his[r]) of its `table` to the same rows of every other
+        rank's table.  Returns the pending work handles (empty when blocking)."""
+        import torch.distributed as dist
+        works = []
+        for r in range(self.world):
+            lo, hi = int(los[r]), int(his[r])
+            if hi <= lo:
+                continue
+            rows = table[lo:hi]
+            src = dist.get_global_rank(self.group, r)
+            if self._host_bounce:
+                # several ranks rehearsing on one GPU under gloo: gloo is unreliable on device
+                # tensors, so the rows travel through a host copy, blocking
+                host = rows.cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                if r != self.me:
+                    rows.copy_(host)
+            elif async_op:
+                works.append(dist.broadcast(rows, src=src, group=self.group, async_op=True))
+            else:
+                dist.broadcast(rows, src=src, group=self.group)
+        return works
+
     def _all_gather_rows(self, table, bounds):
         """Every rank contributes rows [bounds[r], bounds[r+1]) of `table`; afterwards all
-        ranks hold the whole table.  The send buffer never aliases the receive buffer."""
-        if self.world == 1:
-            return
-        import torch.distributed as dist
-        sizes = np.diff(bounds)
-        lo, hi = int(bounds[self.me]), int(bounds[self.me + 1])
-        if sizes.min() == sizes.max():
-            send = table[lo:hi].clone()
-            dist.all_gather_into_tensor(table, send, group=self.group)
-            return
-        width = int(sizes.max())
-        send = torch.zeros((width, table.shape[1]), dtype=table.dtype, device=table.device)
-        send[:hi - lo].copy_(table[lo:hi])
-        recv = torch.empty((self.world * width, table.shape[1]), dtype=table.dtype,
-                           device=table.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
-        for r in range(self.world):
-            if r != self.me and sizes[r]:
-                table[int(bounds[r]):int(bounds[r + 1])].copy_(
-                    recv[r * width:r * width + int(sizes[r])])
+        ranks hold the whole table."""
+        if self.collective:
+            self._bcast_rows(table, bounds[:-1], bounds[1:], False)
 
-    def _start_slab_gather(self, table, sub_all, stages, s, src=None):
-        """Begin the all-gather of slab s (rows sub_all[r, s:s+2] of every rank r) into
-        `table` and return what `_finish_slab_gather` needs.  This rank's rows are taken
-        from `src` (a table indexed like `table`; default `table` itself).  The collective
-        is ordered after the kernels already enqueued on the current stream and runs beside
-        the ones enqueued later."""
-        import torch.distributed as dist
-        lo = sub_all[:, s]
-        sizes = sub_all[:, s + 1] - lo
-        width = int(sizes.max())
-        send, recv = stages[s]
-        mlo, mine = int(lo[self.me]), int(sizes[self.me])
-        send[:mine].copy_((table if src is None else src)[mlo:mlo + mine])
-        # asynchronous where that is the backend's normal mode (RCCL; gloo on host tensors).
-        # gloo with device tensors (several ranks rehearsing on one GPU) is unreliable:
-        # that case goes through host copies, blocking.
-        overlap = dist.get_backend(self.group) == 'nccl' or not table.is_cuda
-        if overlap:
-            work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
-        else:
-            work = None
-            host = torch.empty(recv.shape, dtype=recv.dtype)
-            dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
-            recv.copy_(host)
-        return work, recv, lo, sizes, width
+    def _start_slab_gather(self, table, sub_all, s):
+        """Begin the gather of slab s (rows sub_all[r, s:s+2] of every rank r) into `table`.
+        The broadcasts are ordered after the kernels already enqueued on the current stream
+        and run beside the ones enqueued later; `_finish_gathers` makes the stream wait."""
+        return self._bcast_rows(table, sub_all[:, s], sub_all[:, s + 1], True)
 
-    def _finish_slab_gather(self, table, pending, include_me=False):
-        work, recv, lo, sizes, width = pending
-        if work is not None:
-            work.wait()
-        for r in range(self.world):
-            if (include_me or r != self.me) and sizes[r]:
-                table[int(lo[r]):int(lo[r] + sizes[r])].copy_(
-                    recv[r * width:r * width + int(sizes[r])])
+    def _finish_gathers(self, pending):
+        """Wait for the given gathers.  With `time_gathers` set the time the compute stream
+        spends in these waits (the part of the communication that no kernel hides) is added
+        to `gather_exposed_ms`, measured with events on that stream."""
+        works = [w for p in pending for w in p]
+        timed = self.time_gathers and works
+        if timed:
+            t0 = self._stamp()
+        for w in works:
+            w.wait()
+        if timed:
+            self._gather_stamps.append((t0, self._stamp()))
+
+    def _stamp(self):
+        if self.U.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+        return time.perf_counter()
+
+    def gather_exposed_ms(self, reset=True):
+        """Sum over the half-sweeps since the last reset of the time the compute stream waited
+        for gathers (synchronises the device)."""
+        total = 0.0
+        for a, b in self._gather_stamps:
+            if self.U.is_cuda:
+                b.synchronize()
+                total += a.elapsed_time(b)
+            else:
+                total += (b - a) * 1e3
+        if reset:
+            self._gather_stamps = []
+        return total
 
     # ---- the loop body ------------------------------------------------------
     def half_sweep_users(self):
@@ -263,9 +282,9 @@ class AlsEngine(object):
     def _user_half(self, cur, dst_table, want_err):
         mine = slice(self.ulo, self.uhi)
         return self._half_local(self.plans_u, self.V, cur, dst_table, mine, self.u_sub_all,
-                                self._stage_u, want_err)
+                                want_err)
 
-    def _half_local(self, plans, src, cur, dst_table, mine, sub_all, stages, want_err):
+    def _half_local(self, plans, src, cur, dst_table, mine, sub_all, want_err):
         """The plans index this rank's rows from 0, the gathers index whole tables."""
         sse = None
         pending = []
@@ -276,10 +295,9 @@ class AlsEngine(object):
                 sse = part if sse is None else sse + part
             else:
                 plan.half_sweep(src, dst_local, self.alpha)
-            if self.world > 1:
-                pending.append(self._start_slab_gather(dst_table, sub_all, stages, s))
-        for p in pending:
-            self._finish_slab_gather(dst_table, p)
+            if self.collective:
+                pending.append(self._start_slab_gather(dst_table, sub_all, s))
+        self._finish_gathers(pending)
         return sse
 
     def half_sweep_users_err(self, keep_old=False):
@@ -298,7 +316,7 @@ class AlsEngine(object):
             self._pending = True
         else:
             sse = self._user_half(cur, self.U, True)
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.all_reduce(sse, group=self.group)
         return sse
@@ -316,7 +334,7 @@ class AlsEngine(object):
 
     def half_sweep_items(self):
         self._half_local(self.plans_i, self.U, None, self.V, slice(self.ilo, self.ihi),
-                         self.i_sub_all, self._stage_i, False)
+                         self.i_sub_all, False)
 
     def train_sse_async(self):
         """Sum of squared errors over all stored entries as a 1-element fp64 device
@@ -325,7 +343,7 @@ class AlsEngine(object):
             self._pair_rows = self.csr.expand_rows()
         _, sse = self.backend.sddmm(self.rank, self._pair_rows, self.csr.indices,
                                     self.U[self.ulo:self.uhi], self.V, self.csr.vals, False)
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.all_reduce(sse, group=self.group)
         return sse
@@ -333,7 +351,7 @@ class AlsEngine(object):
     def sum_sq_ratings(self):
         """Sum of the squared stored ratings over all ranks (a float)."""
         t = (self.csr.vals.to(torch.float64) ** 2).sum().reshape(1)
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)
         return float(t.cpu()[0])
