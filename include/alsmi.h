@@ -134,7 +134,11 @@ int alsmi_sddmm(int dtype, int rank, int64_t n_pairs, const int32_t *users,
  * library image (one copy per GPU, held until the process ends), and the call performs no
  * hipMalloc / hipFree.  At most ALSMI_SDDMM_NOALLOC_MAX_PAIRS pairs per call (more is
  * ALSMI_EINVAL).  All calls on one GPU share that array: calls that overlap in time on one
- * GPU (different streams or threads) race on sse_out; pred_out is unaffected. */
+ * GPU (different streams or threads) race on sse_out; pred_out is unaffected.
+ * The FIRST call on a device looks the array's address up (hipGetSymbolAddress, which makes
+ * the runtime load the library's code object there and may allocate inside the runtime):
+ * make one warm-up call per device outside any stream capture; every later call on that
+ * device only enqueues kernels. */
 #define ALSMI_SDDMM_NOALLOC_MAX_PAIRS ((int64_t)1 << 28)
 int alsmi_sddmm_noalloc(int dtype, int rank, int64_t n_pairs, const int32_t *users,
                         const int32_t *items, const void *row_factors, const void *col_factors,
@@ -148,7 +152,10 @@ int alsmi_sddmm_noalloc(int dtype, int rank, int64_t n_pairs, const int32_t *use
  * int32, scores_out [n_sel x k] of dtype.  1 <= k <= min(1024, n_items), n_items <= 16 776 960.
  * workspace: at least
  * alsmi_topk_workspace_bytes(dtype, n_sel, n_items) bytes (the dense n_sel x n_items score
- * block: batch the users accordingly).  Deterministic. */
+ * block: batch the users accordingly).  Deterministic.  Scores are ranked by their bit
+ * pattern in the total order of IEEE 754: -0.0 ranks below +0.0 (they do not tie), and a NaN
+ * score with a clear sign bit ranks above +infinity, i.e. first (one with the sign bit set
+ * below -infinity, last); finite factor tables never produce one. */
 size_t alsmi_topk_workspace_bytes(int dtype, int64_t n_sel, int64_t n_items);
 int alsmi_topk_items(int dtype, int rank, int64_t n_sel, const int32_t *users,
                      const void *user_factors, const void *item_factors, int64_t n_items, int k,

@@ -89,26 +89,9 @@ class ALS(BaseEstimator):
                              'provided.')
         users, items = _check_x(X)
         if not sps.issparse(y):
-            import torch
-            # triplets -> CSR on the device (last write wins, zeros dropped, sorted columns)
             shape = tuple(int(v) for v in shape)
             pairs = dev.upload_triplets(users, items, y, shape, dev.require_gpu())
-            csr = dev.build_csr_device(*pairs, shape, np.float64)
-            m = shape[1]
-            # per-item sums from the item-major copy, one segment per item: the same from run to
-            # run, and about a millisecond for 20 M ratings where adding into the m sums with
-            # atomics (index_add_) took 128 ms on 26 744 items and changed in the last bits
-            if int(csr[1].numel()):
-                cptr, _, cvals = dev.csr_to_csc(csr[0], csr[1], csr[2], shape)
-                counts = (cptr[1:] - cptr[:-1]).to(torch.float64)
-                sums = torch.segment_reduce(cvals, 'sum', offsets=cptr, initial=0.0)
-            else:
-                counts = torch.zeros(m, dtype=torch.float64, device=csr[0].device)
-                sums = torch.zeros_like(counts)
-            item_avg = torch.where(counts > 0, sums / counts.clamp_min(1),
-                                   torch.zeros_like(sums)).cpu().numpy()
-            self._data, self._data_dev = None, (csr, shape)
-            return csr, shape, item_avg, pairs
+            return self._build_from_device_triplets(pairs, shape)
         data = y.tocsr().astype(np.float64)
         if data is y:
             data = data.copy()
@@ -126,10 +109,49 @@ class ALS(BaseEstimator):
         self.data = data
         return (data.indptr, data.indices, data.data), data.shape, item_avg, None
 
+    def _build_from_device_triplets(self, pairs, shape):
+        """(users int32, items int32, y float64) device tensors -> the tuple `_build_data`
+        returns: CSR on the device (last write wins, zeros dropped, sorted columns)."""
+        import torch
+        csr = dev.build_csr_device(*pairs, shape, np.float64)
+        m = shape[1]
+        # per-item sums from the item-major copy, one segment per item: the same from run to
+        # run, and about a millisecond for 20 M ratings where adding into the m sums with
+        # atomics (index_add_) took 128 ms on 26 744 items and changed in the last bits
+        if int(csr[1].numel()):
+            cptr, _, cvals = dev.csr_to_csc(csr[0], csr[1], csr[2], shape)
+            counts = (cptr[1:] - cptr[:-1]).to(torch.float64)
+            sums = torch.segment_reduce(cvals, 'sum', offsets=cptr, initial=0.0)
+        else:
+            counts = torch.zeros(m, dtype=torch.float64, device=csr[0].device)
+            sums = torch.zeros_like(counts)
+        item_avg = torch.where(counts > 0, sums / counts.clamp_min(1),
+                               torch.zeros_like(sums)).cpu().numpy()
+        self._data, self._data_dev = None, (csr, shape)
+        return csr, shape, item_avg, pairs
+
+    def fit_device_triplets(self, users, items, y, shape):
+        """``fit`` for ratings that are already on the device: int32 user and item ids and
+        float64 values, torch tensors on the current GPU, indices inside `shape` (DirtyIMC
+        hands over the residual of its IMC stage this way, src/dimc.py:155-160, without a
+        round trip through the host).  Same semantics as the 1-D ``y`` + ``shape`` form."""
+        import torch
+        shape = tuple(int(v) for v in shape)
+        if users.dtype != torch.int32 or items.dtype != torch.int32 or y.dtype != torch.float64:
+            raise ValueError('users/items must be int32 and y float64 device tensors')
+        if not (users.numel() == items.numel() == y.numel()):
+            raise ValueError('users, items and y must have the same length')
+        self._fit_built(self._build_from_device_triplets((users, items, y), shape), None, None)
+        return self
+
     def fit_transform(self, X, y, shape=None):
         """Factorise the ratings; returns ``(user_feats, item_feats)`` of shapes
         (rank, n_users) and (rank, n_items) (src/als.py:109-171)."""
-        csr, (n, m), item_avg, dev_pairs = self._build_data(X, y, shape)
+        return self._fit_built(self._build_data(X, y, shape), X, y)
+
+    def _fit_built(self, built, X, y):
+        """The sweep loop on ratings in canonical form (src/als.py:143-171)."""
+        csr, (n, m), item_avg, dev_pairs = built
         random_state = check_random_state(self.random_state)
 
         # initial factors: uniform random items with row 0 = mean rating of the
@@ -190,11 +212,20 @@ class ALS(BaseEstimator):
             record(new_rmse)
             diff = rmse - new_rmse
             rmse = new_rmse
-            if (by_tol and not diff > self.tol) or not np.isfinite(new_rmse):
-                if by_tol:
-                    engine.discard_users()
+            if by_tol and (not diff > self.tol or not np.isfinite(new_rmse)):
+                engine.discard_users()
                 pending = False
                 break
+            if not by_tol and not np.isfinite(new_rmse):
+                # a fixed sweep count: the fused float32 error (a difference of three sums)
+                # can overflow where the factors are fine, and the factors it belonged to are
+                # overwritten already.  Keep the NaN in the history and go on; stop only when
+                # the factors themselves are no longer finite.
+                import torch
+                if not bool(torch.isfinite(engine.U).all()) or \
+                        not bool(torch.isfinite(engine.V).all()):
+                    pending = False
+                    break
             if by_tol:
                 engine.commit_users()
             engine.half_sweep_items()
@@ -205,13 +236,15 @@ class ALS(BaseEstimator):
         self.user_feats, self.item_feats = engine.get_factors()
         self.shape_ = (n, m)
         # the device tables stay for predictions (dropped when the host factors change)
-        self._tables = (engine.U, engine.V, id(self.user_feats), id(self.item_feats))
+        self._remember_tables(engine.U, engine.V)
         if dev_pairs is not None and dev_pairs[0].numel() > 0:
             # score(X, y) (src/als.py:169) on the triplets and factor tables still on the device
             du, di, dy = dev_pairs
             _, sse = dev.sddmm(self.rank, du, di, engine.U, engine.V, dy.to(engine.U.dtype),
                                want_pred=False)
             self.reconstruction_err_ = -float(np.sqrt(float(sse.cpu()[0]) / du.numel()))
+        elif X is None:
+            self.reconstruction_err_ = float('nan')  # fit_device_triplets without a sample
         else:
             self.reconstruction_err_ = self.score(X, y)
         return self.user_feats, self.item_feats
@@ -230,22 +263,47 @@ class ALS(BaseEstimator):
         items = np.where(items < 0, items + m, items).astype(np.int32)
         tables = self._cached_tables()
         if tables is None:
-            tables = (dev.factors_to_device(self.user_feats, self.dtype, device),
-                      dev.factors_to_device(self.item_feats, self.dtype, device),
-                      id(self.user_feats), id(self.item_feats))
-            self._tables = tables
+            tables = self._remember_tables(
+                dev.factors_to_device(self.user_feats, self.dtype, device),
+                dev.factors_to_device(self.item_feats, self.dtype, device))
         U, V = tables[:2]
         pred, _ = dev.sddmm(self.rank, torch.from_numpy(users).to(device),
                             torch.from_numpy(items).to(device), U, V)
         return pred.to(torch.float64).cpu().numpy()
 
+    @staticmethod
+    def _fingerprint(feats):
+        """A cheap signature of a (rank, n) host array: its shape and the sums of its first
+        and last row and column (O(rank + n) instead of a pass over the whole array)."""
+        feats = np.asarray(feats)
+        if feats.size == 0:
+            return (feats.shape,)
+        return (feats.shape, float(feats[0].sum()), float(feats[-1].sum()),
+                float(feats[:, 0].sum()), float(feats[:, -1].sum()))
+
+    def _remember_tables(self, U, V):
+        """Keep the device copies of the factor tables together with the host arrays they
+        were made from (strong references: a later array cannot reuse their identity) and a
+        signature of their contents."""
+        self._tables = (U, V, self.user_feats, self.item_feats,
+                        self._fingerprint(self.user_feats), self._fingerprint(self.item_feats))
+        return self._tables
+
+    def invalidate(self):
+        """Drop the device copies of the factors (they are rebuilt on the next prediction, and
+        until then hold rank x (users + items) elements of device memory).  Call it after
+        editing ``user_feats`` / ``item_feats`` in place in a way the signature check cannot
+        see: the check compares the array objects, their shapes and the sums of the first and
+        last row and column."""
+        self._tables = None
+
     def _cached_tables(self):
         """The device copies of the factor tables if they still belong to the host arrays
-        (same array objects, same shapes), else None."""
+        (the same array objects with an unchanged signature), else None."""
         t = getattr(self, '_tables', None)
-        if t is None or t[2] != id(self.user_feats) or t[3] != id(self.item_feats) or \
-                t[0].shape[0] != self.user_feats.shape[1] or \
-                t[1].shape[0] != self.item_feats.shape[1]:
+        if t is None or t[2] is not self.user_feats or t[3] is not self.item_feats or \
+                t[4] != self._fingerprint(self.user_feats) or \
+                t[5] != self._fingerprint(self.item_feats):
             return None
         return t
 

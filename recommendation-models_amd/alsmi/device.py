@@ -239,15 +239,14 @@ def _sparse_workspace(n_entries, device):
     return ws
 
 
-def upload_triplets(users, items, y, shape, device):
-    """Host (users, items, y) -> device (int32, int32, float64) with the reference's index
-    rules (negative indices wrap, out-of-range raises IndexError)."""
+def upload_pairs(users, items, shape, device):
+    """Host (users, items) -> device int32 tensors with the reference's index rules (negative
+    indices wrap, out-of-range raises IndexError)."""
     n, m = int(shape[0]), int(shape[1])
     users = np.asarray(users).ravel()
     items = np.asarray(items).ravel()
-    y = np.asarray(y, dtype=np.float64).ravel()
-    if not (users.size == items.size == y.size):
-        raise ValueError('users, items and y must have the same length')
+    if users.size != items.size:
+        raise ValueError('users and items must have the same length')
     if users.size and (users.min() < -n or users.max() >= n or
                        items.min() < -m or items.max() >= m):
         raise IndexError('index out of bounds for shape {}'.format((n, m)))
@@ -255,6 +254,15 @@ def upload_triplets(users, items, y, shape, device):
     d_items = torch.from_numpy(np.ascontiguousarray(items)).to(device)
     d_users = torch.where(d_users < 0, d_users + n, d_users).to(torch.int32)
     d_items = torch.where(d_items < 0, d_items + m, d_items).to(torch.int32)
+    return d_users, d_items
+
+
+def upload_triplets(users, items, y, shape, device):
+    """Host (users, items, y) -> device (int32, int32, float64); see upload_pairs."""
+    y = np.asarray(y, dtype=np.float64).ravel()
+    if not (np.size(users) == np.size(items) == y.size):
+        raise ValueError('users, items and y must have the same length')
+    d_users, d_items = upload_pairs(users, items, shape, device)
     return d_users, d_items, torch.from_numpy(y).to(device)
 
 

@@ -88,10 +88,29 @@ class DirtyIMC(BaseEstimator):
         attribute = self._attribute_form(x, y_, users, items, shape)
         prob = self._problem(x, y_, users, items, r_, attribute, group=default_group())
         self.imc._fit_on(prob, Z)
+        self.als.shape_ = tuple(int(v) for v in shape)
+        if prob.group is None:
+            # One rank: the residual r - x^T Z y (src/dimc.py:155-160) never leaves the device.
+            if attribute:
+                # The IMC problem already holds the samples there, grouped by user; that order
+                # keeps the caller's order among the samples of one (user, item) pair, which is
+                # all the reference's element-by-element fill (last write wins) depends on.
+                du, di, dr = prob.grouped_triplets_dev()
+            else:
+                # per-sample feature rows: every sample is its own "user" of the IMC problem,
+                # so its grouped order is the caller's order; the real index pairs go up once
+                from . import device as dev
+                du, di = dev.upload_pairs(users, items, self.als.shape_, prob.device)
+                dr = prob.ratings.to(du.device, prob._torch.float64)
+            resid = dr - prob.predict_samples_grouped_dev(self.imc.Z)
+            self.als.fit_device_triplets(du, di, resid, self.als.shape_)
+            # score(X, y) (src/dimc.py:161): r - (uv + xzy) = residual - uv, and the ALS stage
+            # has just scored its own predictions against exactly that residual
+            self.reconstruction_err_ = self.als.reconstruction_err_
+            return self.imc.Z, self.als.user_feats, self.als.item_feats
         xzy = prob.predict_samples(self.imc.Z)
         self.als.fit((users, items), r_ - xzy, shape=shape)
-        self.als.shape_ = tuple(int(v) for v in shape)
-        # score(X, y) (src/dimc.py:160) from the parts at hand: the same samples' x^T Z y are in
+        # score(X, y) (src/dimc.py:161) from the parts at hand: the same samples' x^T Z y are in
         # xzy already, so the IMC problem is not grouped and uploaded a second time
         uv = self.als._pair_predictions(users, items)
         self.reconstruction_err_ = -root_mean_squared_error(r_, uv + xzy)

@@ -111,15 +111,28 @@ class AlsEngine(object):
         self.csr = b.make_side(csr[0], csr[1], csr[2], self.uhi - self.ulo, self.m, self.dtype)
         self.csc = b.make_side(csc[0], csc[1], csc[2], self.ihi - self.ilo, self.n, self.dtype)
         # With several ranks each half runs as a few row slabs, balanced by entries, and the
-        # all-gather of one slab travels while the next is computed (the user table is the
-        # large one: N x 35 MB at 138 493 users per rank and rank 64, 5 GB at 10 M users and
-        # rank 128).
+        # gather of one slab travels while the next is computed.  A slab is a launch of its
+        # own (138 493 users, 20 M entries, rank 64 on one GPU: 1.08 / 1.18 / 1.51 ms for 1 / 2 /
+        # 4 user slabs; 1.25 M users, 125 M entries, rank 128: 17.0 / 17.7 / 17.6 ms), so the
+        # count follows the bytes this rank contributes to the gather: 4 slabs from 256 MB
+        # (640 MB per rank at 10 M users over 8 GPUs and rank 128), 2 from 16 MB (35 MB at
+        # 138 493 users per rank and rank 64), else 1.
+        self.kp = b.padded_rank(self.rank)
+
+        def slabs_for(rows, env):
+            forced = int(os.environ.get(env, '0'))
+            if forced:
+                return forced
+            if not self.collective:
+                return 1
+            nbytes = rows * self.kp * self.dtype.itemsize
+            return 4 if nbytes >= (256 << 20) else 2 if nbytes >= (16 << 20) else 1
+
         if user_slabs is None:
-            user_slabs = int(os.environ.get('ALSMI_USER_SLABS', '0')) or \
-                (4 if self.collective else 1)
+            # (the largest rank's rows: every rank must arrive at the same count)
+            user_slabs = slabs_for(int(np.diff(self.user_bounds).max()), 'ALSMI_USER_SLABS')
         if item_slabs is None:
-            item_slabs = int(os.environ.get('ALSMI_ITEM_SLABS', '0')) or \
-                (2 if self.collective else 1)
+            item_slabs = slabs_for(int(np.diff(self.item_bounds).max()), 'ALSMI_ITEM_SLABS')
         self.u_sub = split_by_nnz(self.csr.indptr_host, max(1, int(user_slabs)))
         self.i_sub = split_by_nnz(self.csc.indptr_host, max(1, int(item_slabs)))
         self.plans_u = [b.make_plan(self.csr, self.rank, chunk, int(lo), int(hi))
@@ -127,7 +140,6 @@ class AlsEngine(object):
         self.plans_i = [b.make_plan(self.csc, self.rank, chunk, int(lo), int(hi))
                         for lo, hi in zip(self.i_sub[:-1], self.i_sub[1:])]
         self.plan_i = self.plans_i[0]
-        self.kp = b.padded_rank(self.rank)
         self.U = b.zeros(self.n, self.kp, self.dtype)
         self.V = b.zeros(self.m, self.kp, self.dtype)
         self._U_next, self._pending = None, False

@@ -27,7 +27,7 @@ from sklearn.utils.validation import check_is_fitted
 
 from . import _lib
 from . import device as dev
-from .engine import default_group
+from .engine import default_group, force_collectives
 from .utils import _check_x, root_mean_squared_error
 
 INTEGER_TYPES = (numbers.Integral, np.integer)
@@ -48,7 +48,7 @@ class ImcProblem(object):
         if group is not None:
             import torch.distributed as dist
             shard = (dist.get_rank(group), dist.get_world_size(group))
-            if shard[1] == 1:
+            if shard[1] == 1 and not force_collectives():
                 self.group, shard = None, None
         self.dtype = np.dtype(dtype)
         X_attrs = np.atleast_2d(np.asarray(X_attrs, dtype=np.float64))
@@ -79,9 +79,11 @@ class ImcProblem(object):
             items_g, ratings_g = items[self.order].astype(np.int32), ratings[self.order]
         # this rank's users [ulo, uhi) and their samples [slo, shi) of the grouped order
         self.ulo, self.uhi, self.slo, self.shi = 0, self.n_users, 0, self.n_samples
+        self._sample_bounds = np.array([0, self.n_samples], dtype=np.int64)
         if shard is not None:
             from .engine import split_by_nnz
             bounds = split_by_nnz(indptr, int(shard[1]))
+            self._sample_bounds = indptr[bounds]  # every rank's samples of the grouped order
             self.ulo, self.uhi = int(bounds[shard[0]]), int(bounds[shard[0] + 1])
             self.slo, self.shi = int(indptr[self.ulo]), int(indptr[self.uhi])
             indptr = indptr[self.ulo:self.uhi + 1] - self.slo
@@ -117,6 +119,7 @@ class ImcProblem(object):
         self.ratings_host = None
         self.order = None
         self.ulo, self.uhi, self.slo, self.shi = 0, self.n_users, 0, self.n_samples
+        self._sample_bounds = np.array([0, self.n_samples], dtype=np.int64)
         self.n_local_users, self.n_local_samples = self.n_users, self.n_samples
         td = dev.torch_dtype(self.dtype)
         self.indptr = indptr.to(self.device, torch.int64).contiguous()
@@ -167,7 +170,10 @@ class ImcProblem(object):
             dev._ptr(self.Y), dev._ptr(Md), dev._ptr(out), dev._ptr(local_pred),
             dev._ptr(sse), dev._ptr(self.workspace), dev._stream()), 'alsmi_imc_eval')
 
-    def _eval(self, mode, M, want_out=True, want_sse=False, want_pred=False, ratings=None):
+    def _eval_dev(self, mode, M, want_out=True, want_sse=False, want_pred=False, ratings=None):
+        """One evaluation, results left on the device: (out [p x q] or None, sse [1] fp64 or
+        None, predictions of ALL samples in the grouped order or None); None for everything
+        when there are no samples."""
         torch = self._torch
         M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(self.p, self.q))
         # the p x q operand and result and the scalar live in buffers kept across evaluations
@@ -178,26 +184,47 @@ class ImcProblem(object):
                 torch.empty((self.p, self.q), dtype=self._td, device=self.device),
                 torch.empty((self.p, self.q), dtype=self._td, device=self.device),
                 torch.empty(1, dtype=torch.float64, device=self.device))
+        if self.n_users == 0 or self.n_samples == 0:
+            return None, None, None
         Md = bufs[0]
         Md.copy_(torch.from_numpy(M))
         out = bufs[1].zero_() if want_out else None
         sse = bufs[2].zero_() if want_sse else None
-        # predictions: this rank fills its samples' slots of the full (grouped) vector
-        pred = torch.zeros(self.n_samples, dtype=self._td, device=self.device) \
-            if want_pred else None
+        # predictions: this rank fills its samples' slots of the full (grouped) vector, the
+        # other ranks' slots arrive by the gather below
+        # (a shard without a group leaves them zero: its caller adds the shards up)
+        alloc = torch.zeros if self.group is None and self.n_local_samples != self.n_samples \
+            else torch.empty
+        pred = alloc(self.n_samples, dtype=self._td, device=self.device) if want_pred else None
         r = self.ratings if ratings is None else ratings
-        if self.n_users == 0 or self.n_samples == 0:
-            zero = np.zeros((self.p, self.q))
-            return (zero if want_out else None, 0.0 if want_sse else None,
-                    np.zeros(0) if want_pred else None)
         if self.n_local_users > 0 and self.n_local_samples > 0:
             local_pred = pred[self.slo:self.shi] if want_pred else None
             self._run(mode, Md, r, out, local_pred, sse)
         if self.group is not None:
             import torch.distributed as dist
-            for t in (out, sse, pred):
+            for t in (out, sse):
                 if t is not None:
                     dist.all_reduce(t, group=self.group)
+            if pred is not None:
+                # all-gather-v of the ranks' slices: one broadcast per owner straight into its
+                # slots (1/N of the vector each, where an all-reduce of a zero-filled vector
+                # moved all of it through every rank)
+                sb = self._sample_bounds
+                for k in range(sb.size - 1):
+                    if sb[k + 1] > sb[k]:
+                        dist.broadcast(pred[int(sb[k]):int(sb[k + 1])],
+                                       src=dist.get_global_rank(self.group, k), group=self.group)
+        return out, sse, pred
+
+    def _eval(self, mode, M, want_out=True, want_sse=False, want_pred=False, ratings=None):
+        """`_eval_dev` with the results brought to the host (float64; predictions in the
+        caller's sample order)."""
+        torch = self._torch
+        out, sse, pred = self._eval_dev(mode, M, want_out, want_sse, want_pred, ratings)
+        if self.n_users == 0 or self.n_samples == 0:
+            zero = np.zeros((self.p, self.q))
+            return (zero if want_out else None, 0.0 if want_sse else None,
+                    np.zeros(0) if want_pred else None)
         out_h = out.to(torch.float64).cpu().numpy() if want_out else None
         sse_h = float(sse.cpu()[0]) if want_sse else None
         pred_h = None
@@ -313,6 +340,26 @@ class ImcProblem(object):
         """x_e^T Z y_e for every sample, in the caller's sample order."""
         _, _, pred = self._eval(1, Z, want_out=False, want_pred=True)
         return pred
+
+    def predict_samples_grouped_dev(self, Z):
+        """x_e^T Z y_e for every sample as a float64 device tensor in the GROUPED order (the
+        samples user by user, each user's in the caller's order: the order of
+        ``grouped_triplets_dev``)."""
+        _, _, pred = self._eval_dev(1, Z, want_out=False, want_pred=True)
+        if pred is None:
+            return self._torch.zeros(0, dtype=self._torch.float64, device=self.device)
+        return pred.to(self._torch.float64)
+
+    def grouped_triplets_dev(self):
+        """(users int32, items int32, ratings float64) of this rank's samples on the device, in
+        the grouped order; only for an unsharded problem (item ids are then global)."""
+        if self.n_local_samples != self.n_samples or int(self.Y.shape[0]) != self.n_items:
+            raise RuntimeError('the samples of a sharded problem are not all on this rank')
+        torch = self._torch
+        users = torch.repeat_interleave(
+            torch.arange(self.n_users, dtype=torch.int32, device=self.device),
+            self.indptr[1:] - self.indptr[:-1], output_size=self.n_samples)
+        return users, self.items, self.ratings.to(torch.float64)
 
     def sse(self, Z):
         _, sse, _ = self._eval(0, Z, want_out=False, want_sse=True)

@@ -49,7 +49,8 @@ def worker(rank_id, world, port, case, out_dir):
         seed, n, m, nnz, rank, extra = case
         P = random_problem(seed, n, m, nnz, rank, **extra)
         eng = AlsEngine.from_global(P['indptr'], P['indices'], P['vals'], (n, m), rank, 0.1,
-                                    group=dist.group.WORLD, backend=OracleBackend())
+                                    group=dist.group.WORLD, backend=OracleBackend(),
+                                    user_slabs=4, item_slabs=2)
         assert eng.nnz == int(P['indptr'][-1])
         eng.set_factors(np.zeros_like(P['U']), P['V'])
         hist = []

@@ -454,3 +454,32 @@ def test_fp32_tol_loop_on_exactly_low_rank_ratings(gpu):
     np.testing.assert_allclose(p0, als.user_feats[:, 3].dot(als.item_feats[:, 5]), rtol=1e-5)
     als.user_feats = als.user_feats * 2.0
     np.testing.assert_allclose(als.predict_one(3, 5), 2.0 * p0, rtol=1e-6)
+
+
+def test_in_place_edits_of_the_host_factors_are_seen(gpu):
+    """Predictions come from device copies of user_feats / item_feats that are kept between
+    calls; an in-place edit of the host arrays, a replaced array and invalidate() must all
+    lead to predictions from the current factors (src/als.py:316-321 reads them per call)."""
+    from alsmi import ALS
+    rng = np.random.default_rng(8)
+    n, m, nnz = 60, 40, 700
+    flat = rng.choice(n * m, size=nnz, replace=False)
+    users, items = flat // m, flat % m
+    vals = rng.integers(1, 6, nnz).astype(np.float64)
+    als = ALS(rank=5, random_state=0, max_iter=3).fit((users, items), vals, shape=(n, m))
+    pairs = (users[:50], items[:50])
+    want = lambda: (als.user_feats[:, pairs[0]] * als.item_feats[:, pairs[1]]).sum(0)
+    np.testing.assert_allclose(als._predict(pairs), want(), rtol=1e-12)
+    als.item_feats *= 2.0                          # in place: same array object
+    np.testing.assert_allclose(als._predict(pairs), want(), rtol=1e-12)
+    als.user_feats[:, 0] = 7.0                     # one column, in place
+    np.testing.assert_allclose(als._predict((np.zeros(5, int), np.arange(5))),
+                               (als.user_feats[:, [0]] * als.item_feats[:, :5]).sum(0), rtol=1e-12)
+    als.user_feats = als.user_feats * 0.5          # a new array object
+    np.testing.assert_allclose(als._predict(pairs), want(), rtol=1e-12)
+    # an edit in the interior escapes the signature (first/last row and column sums): the
+    # documented way is invalidate()
+    als.item_feats[2, 7] += 1.0
+    als.invalidate()
+    np.testing.assert_allclose(als._predict(pairs), want(), rtol=1e-12)
+    assert als._cached_tables() is not None and als._cached_tables()[2] is als.user_feats

@@ -56,7 +56,8 @@ def test_forced_gathers_on_rccl_match_the_plain_path(rccl_group, dtype):
     V0 = np.random.RandomState(3).rand(rank, m)
 
     def run(group):
-        eng = AlsEngine(P['csr'], P['csc'], P['shape'], rank, 0.1, dtype=dtype, group=group)
+        eng = AlsEngine(P['csr'], P['csc'], P['shape'], rank, 0.1, dtype=dtype, group=group,
+                        user_slabs=4 if group else None, item_slabs=2 if group else None)
         eng.set_factors(np.zeros((rank, n)), V0)
         eng.time_gathers = eng.collective
         eng.half_sweep_users()

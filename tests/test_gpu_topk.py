@@ -97,3 +97,53 @@ def test_als_recommend(golden):
         als.recommend([0], k=4)
     with pytest.raises(IndexError):
         als.recommend([2], k=1)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+@pytest.mark.parametrize('k', [10, 100])
+def test_topk_ties_across_the_kth_score(dtype, k):
+    """Many items with EXACTLY the same score, so that the k-th score is shared by items
+    inside and outside the list: of the equal items the smallest ids are returned, in
+    ascending order (the ordered scan of the select kernel), also when every score is equal."""
+    import torch
+    from alsmi import device as dev
+    device = dev.require_gpu()
+    rng = np.random.default_rng(k)
+    rank, n, m = 12, 40, 3000
+    U = rng.standard_normal((rank, n))
+    base = rng.standard_normal(rank)
+    V = np.tile(base[:, None], (1, m))             # 200 groups of 15 identical items each
+    groups = rng.permutation(m) % 200
+    V += 0.01 * rng.standard_normal((rank, 200))[:, groups]
+    Ud = dev.factors_to_device(U, dtype, device)
+    Vd = dev.factors_to_device(V, dtype, device)
+    users = np.arange(n, dtype=np.int32)
+    items, scores = dev.topk_items(rank, torch.from_numpy(users).to(device), Ud, Vd, k)
+    items, scores = items.cpu().numpy().astype(np.int64), scores.to(torch.float64).cpu().numpy()
+    # the kernel's own scores for every item (k = m gives all of them), so that equality is
+    # exact equality of what the select saw
+    if m <= 1024:
+        raise AssertionError('the case needs m above the k limit')
+    full_i, full_s = dev.topk_items(rank, torch.from_numpy(users).to(device), Ud, Vd, 1024)
+    for r in range(n):
+        seen = dict(zip(full_i[r].cpu().numpy().tolist(),
+                        full_s[r].to(torch.float64).cpu().numpy().tolist()))
+        # group structure: items of one group share one score bit for bit
+        by_score = {}
+        for it, sc in seen.items():
+            by_score.setdefault(sc, []).append(it)
+        assert max(len(v) for v in by_score.values()) >= 10
+        assert (np.diff(scores[r]) <= 0).all()
+        kth = scores[r, -1]
+        inside = items[r][scores[r] == kth]
+        assert (np.diff(inside) > 0).all()
+        # every item with the k-th score that was left out has a larger id than those kept
+        same_group = np.flatnonzero(groups == groups[inside[0]])
+        np.testing.assert_array_equal(inside, np.sort(same_group)[:inside.size])
+        # inside a run of equal scores the ids ascend
+        tie = np.diff(scores[r]) == 0
+        assert (np.diff(items[r])[tie] > 0).all()
+    # all scores equal: the first k item ids
+    Vc = dev.factors_to_device(np.tile(base[:, None], (1, m)), dtype, device)
+    items, _ = dev.topk_items(rank, torch.from_numpy(users[:3]).to(device), Ud, Vc, k)
+    np.testing.assert_array_equal(items.cpu().numpy(), np.tile(np.arange(k), (3, 1)))

@@ -47,12 +47,27 @@ def test_noalloc_sddmm_equals_workspace_sddmm(dtype, rank):
                      device=device)
     # first call: enough pairs that every block of the capped grid writes a partial
     # (2048 blocks x 256 pairs); second call: a handful of pairs, far fewer blocks
+    free_before = None
     for n_pairs in (2048 * 256 * 2 + 77, 1000, 3):
         users = torch.randint(0, n, (n_pairs,), generator=g, device=device).to(torch.int32)
         items = torch.randint(0, m, (n_pairs,), generator=g, device=device).to(torch.int32)
         vals = torch.randn(n_pairs, generator=g, device=device, dtype=td)
         want_pred, want_sse = _call(lib, False, code, rank, users, items, U, V, vals, ws, torch)
         pred, sse = _call(lib, True, code, rank, users, items, U, V, vals, None, torch)
+        if free_before is not None:
+            # after the first (warm-up) call on this device a call takes no device memory:
+            # the driver's free-byte count is the same before and after it (the tensors of
+            # this test come from torch's cache, which holds its blocks across the calls)
+            torch.cuda.synchronize()
+            before = torch.cuda.mem_get_info()[0]
+            vp = lambda t: ctypes.c_void_p(t.data_ptr())
+            for _ in range(3):                      # (into the outputs at hand: no torch allocation)
+                rc = lib.alsmi_sddmm_noalloc(code, rank, n_pairs, vp(users), vp(items), vp(U),
+                                             vp(V), vp(vals), vp(pred), vp(sse), None)
+                assert rc == 0
+            torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info()[0] == before
+        free_before = True
         assert torch.equal(pred, want_pred)
         assert float(sse.cpu()[0]) == float(want_sse.cpu()[0])
         assert float(sse.cpu()[0]) > 0
