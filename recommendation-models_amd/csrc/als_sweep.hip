@@ -1230,6 +1230,13 @@ __device__ unsigned long long g_phase[8];
 #define PHASE_ADD(pc, slot, a, b)
 #endif
 
+// 1: the block row right of the pivot block is eliminated as one product with inv(L_kk) on the
+// matrix core (PivotBlock below); 0: it takes the sixteen rank-one steps with the pivot block
+// (the earlier form, kept for timing comparisons).
+#ifndef SOLVE_ZPROD
+#define SOLVE_ZPROD 1
+#endif
+
 // Lane constants of the block solver.
 struct SolveLane {
     int lane, g, q, irow, addr_row, addr_col;
@@ -1268,20 +1275,41 @@ struct PivotBlock {
             const float inv = __builtin_amdgcn_rcpf(d);  // 1 ulp; a multiplier needs no more
             const float m = (L.irow > p) ? -cola * inv : 0.0f;
             // all row fetches of the step first, so that their latencies overlap
+            constexpr int JEND = SOLVE_ZPROD ? K + 1 : NV;  // tiles that take the sixteen steps
             float rows[NV + 1];
 #pragma unroll
-            for (int j = K; j < NV; ++j)
+            for (int j = K; j < JEND; ++j)
                 rows[j] = bperm(L.addr_row + 64 * gp, G.acc[tri_index(K, j, NV)][rp]);
             rows[NV] = bperm(L.addr_row + 64 * gp, rt[rp]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = K; j < NV; ++j) {
+            for (int j = K; j < JEND; ++j) {
                 f4 &t = G.acc[tri_index(K, j, NV)];
                 t = __builtin_amdgcn_mfma_f32_4x4x1f32(m, rows[j], t, 0, 0, 0);
             }
             rt = __builtin_amdgcn_mfma_f32_4x4x1f32(m, rows[NV], rt, 0, 0, 0);
             mfma_f32_fence<1>();
             dv[rp] = (g == gp) ? inv : dv[rp];
+        }
+        if constexpr (SOLVE_ZPROD && K + 1 < NV) {
+            // The sixteen steps ran on [S_kk | R] alone.  R is now E = inv(L_kk) (its last column,
+            // which carried the right-hand side, is e_15 in truth), and the rest of the block
+            // row takes all sixteen steps at once as the product Z_J = E S_kJ: two tiles in this
+            // layout give X^T Y, so E goes through the matrix core once against the identity
+            // (E^T I, exact) and then (E^T)^T S_kJ — four matrix instructions per tile instead
+            // of sixteen rank-one updates with a cross-lane fetch each.
+            f4 et, ident;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool diag = 4 * g + r == q;
+                ident[r] = diag ? 1.0f : 0.0f;
+                et[r] = L.last_col ? ((4 * g + r == 15) ? 1.0f : 0.0f) : rt[r];
+            }
+            const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            et = mfma_xty(et, ident, zero);
+#pragma unroll
+            for (int j = K + 1; j < NV; ++j)
+                G.acc[tri_index(K, j, NV)] = mfma_xty(et, G.acc[tri_index(K, j, NV)], zero);
         }
         PHASE_T(tc1);
         PHASE_ADD(L.pc, 4, tc0, tc1);
