@@ -52,6 +52,8 @@ CONFIGS = {
                  workload='ALS rank 8, synthetic 300x200, 6000 nnz per rank (rehearsal size)'),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec
+# Dense matrix-pipe peaks (FLOP/s): 16-bit matrix cores, fp32 (matrix = vector rate), fp64 matrix
+PEAK_F16_MATRIX, PEAK_F32, PEAK_F64 = 2.5e15, 157.3e12, 78.6e12
 
 
 def half_sweep_bytes(nnz, rows, kp, s):
@@ -64,6 +66,41 @@ def sddmm_bytes(nnz, rows, kp, s):
     """Training-error pass with row reuse: per entry one item factor row, two int32
     indices and the rating; per user row its factor vector once."""
     return nnz * (kp * s + 8 + s) + rows * kp * s
+
+
+def side_flops(indptr_host, rank, kp, dtype):
+    """Arithmetic one half-sweep of a side issues, from its row lengths.
+
+    Gram build: only the upper tiles of a row's kp x kp matrix are formed,
+    2 * entries * kp^2 * (NV+1)/(2 NV) with NV = kp/16; a short row (fp32, padded rank 64 or
+    128, at most min(rank, 48 or 64) entries) forms the n x n matrix of its neighbours
+    instead, n = its entries padded to 16.  Solve: 2 (s^3/3 + 2 s^2) per row of an s x s system.
+    Returns (gram_flops, solve_flops, matrix products issued per Gram product): in fp32 every
+    Gram product is 3 products of the two-way fp16 split on the 16-bit matrix cores (4 at
+    padded rank 128, whose concatenated operands form all four)."""
+    deg = np.diff(np.asarray(indptr_host)).astype(np.float64)
+    nv = kp // 16
+    tri = (nv + 1) / (2.0 * nv)
+    f32 = np.dtype(dtype) == np.float32
+    dual_max = min(rank, 48 if kp == 64 else 64) if (f32 and kp in (64, 128)) else 0
+    short = (deg > 0) & (deg <= dual_max)
+    n_pad = 16.0 * np.ceil(deg[short] / 16.0)
+    nd = n_pad / 16.0
+    gram = 2.0 * deg[~short].sum() * kp * kp * tri + (2.0 * n_pad * n_pad * kp * (nd + 1) / (2 * nd)).sum()
+    s_long = float(kp)
+    solve = 2.0 * ((deg > 0) & ~short).sum() * (s_long ** 3 / 3 + 2 * s_long ** 2) + \
+        (2.0 * (n_pad ** 3 / 3 + 2 * n_pad ** 2)).sum()
+    products = (4 if kp == 128 else 3) if f32 else 1
+    return float(gram), float(solve), products
+
+
+def matrix_roof_seconds(gram, solve, products, dtype):
+    """Time the matrix pipes need for that arithmetic at their dense peaks: fp32 Gram products
+    on the 16-bit matrix cores, the fp32 solve at the fp32 matrix/vector rate; fp64 everything
+    on the fp64 matrix pipe."""
+    if np.dtype(dtype) == np.float32:
+        return gram * products / PEAK_F16_MATRIX + solve / PEAK_F32
+    return (gram + solve) / PEAK_F64
 
 
 def kernel_source_sha():
@@ -213,19 +250,89 @@ def timed_sweeps(engine, steps, warmup, fused, barrier, cuda):
     return elapsed, t_user, t_item, t_sse, rmse
 
 
-def side_report(ms, algo_bytes, counters, side):
-    """Per-side roofline entry: algorithmic rate, and from the committed counters (when they
-    belong to this build) the HBM-side rate and what the kernel is therefore bound by."""
-    out = {'ms': ms * 1e3, 'GBps': algo_bytes / ms / 1e9, 'algorithmic_bytes': algo_bytes}
+def side_report(sec, algo_bytes, flops, dtype, counters, side):
+    """Per-side roofline entry.  Two roofs from the algorithmic model: the bytes at the HBM
+    peak and the arithmetic at the matrix pipes' dense peaks; `bound` names the larger one
+    and `frac` is that roof's time over the measured time.  `algorithmic_GBps` is the
+    uncached-model rate (every stored entry fetches one factor row) and can exceed what HBM
+    delivers when the gathered table is cache resident; the measured HBM bytes of the committed
+    counter passes (when they belong to this build) stand beside it."""
+    gram, solve, products = flops
+    hbm_s = algo_bytes / (HBM_PEAK_GBS * 1e9)
+    mat_s = matrix_roof_seconds(gram, solve, products, dtype)
+    out = {'ms': sec * 1e3, 'algorithmic_bytes': algo_bytes, 'algorithmic_GBps': algo_bytes / sec / 1e9,
+           'gram_flops': gram, 'solve_flops': solve, 'matrix_products_per_gram_product': products,
+           'hbm_roof_ms': hbm_s * 1e3, 'matrix_roof_ms': mat_s * 1e3,
+           'bound': 'hbm' if hbm_s >= mat_s else 'mfma', 'frac': max(hbm_s, mat_s) / sec}
     c = (counters or {}).get(side)
     if c:
         out['hbm_measured_bytes'] = c['hbm_bytes']
-        out['hbm_measured_GBps'] = c['hbm_bytes'] / ms / 1e9
+        out['hbm_measured_GBps'] = c['hbm_bytes'] / sec / 1e9
+        out['hbm_measured_frac_of_peak'] = c['hbm_bytes'] / sec / 1e9 / HBM_PEAK_GBS
         out['mfma_util'] = c.get('mfma_util')
-        # traffic well below the algorithmic bytes: the gathered table is served from
-        # L2 / Infinity Cache and the launch is bound by instruction issue, not by HBM
-        out['bound'] = 'hbm' if c['hbm_bytes'] >= 0.5 * algo_bytes else 'issue/l2'
+        # traffic well below the algorithmic bytes: the gathered table is served from L2 /
+        # Infinity Cache and neither roof binds; what does is instruction issue
+        out['limited_by'] = 'hbm' if c['hbm_bytes'] >= 0.5 * algo_bytes else \
+            'instruction issue / cache gather (the gathered table is cache resident)'
     return out
+
+
+def roofline_report(engine, dtype, t_user, t_item, fused, counters):
+    """The `roofline` object of the JSON line for one engine's measured half-sweep times."""
+    s = np.dtype(dtype).itemsize
+    kp = engine.kp
+    b_user = half_sweep_bytes(engine.csr.nnz, engine.csr.n_rows, kp, s)
+    if fused:
+        b_user += engine.csr.n_rows * kp * s  # the replaced vectors are read for the error
+    b_item = half_sweep_bytes(engine.csc.nnz, engine.csc.n_rows, kp, s)
+    f_user = side_flops(engine.csr.indptr_host, engine.rank, kp, dtype)
+    f_item = side_flops(engine.csc.indptr_host, engine.rank, kp, dtype)
+    user = side_report(t_user, b_user, f_user, dtype, counters, 'user_side')
+    item = side_report(t_item, b_item, f_item, dtype, counters, 'item_side')
+    t = t_user + t_item
+    hbm_s = (b_user + b_item) / (HBM_PEAK_GBS * 1e9)
+    mat_s = (user['matrix_roof_ms'] + item['matrix_roof_ms']) * 1e-3
+    traffic = None
+    if counters and 'user_side' in counters:
+        traffic = (counters['user_side']['hbm_bytes'] + counters['item_side']['hbm_bytes']) / 2
+    out = {'traffic': traffic,
+           'hbm_roof_ms_per_sweep': hbm_s * 1e3, 'matrix_roof_ms_per_sweep': mat_s * 1e3,
+           'algorithmic_GBps': (b_user + b_item) / t / 1e9}
+    if hbm_s >= mat_s:
+        achieved = (b_user + b_item) / t / 1e9
+        out.update(bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                   frac=achieved / HBM_PEAK_GBS)
+    else:
+        # credited arithmetic = what the model prices (upper Gram tiles + solves); the peak is
+        # the rate at which the matrix pipes would finish exactly that work
+        work = sum(f[0] + f[1] for f in (f_user, f_item))
+        achieved, peak = work / t / 1e12, work / mat_s / 1e12
+        out.update(bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak)
+    out.update({
+        'note': 'two roofs from the algorithmic model: bytes (uncached: every stored entry fetches '
+                'one factor row; per half-sweep nnz*(ld*s+4+s) + rows*(ld*s+8)) at the 8 TB/s HBM '
+                'peak, and the issued arithmetic at the dense matrix-pipe peaks (2.5 PFLOP/s 16-bit, '
+                '157.3 TFLOP/s fp32, 78.6 TFLOP/s fp64); bound = the larger, frac = its time / the '
+                'HIP-event time.  Where the measured HBM traffic (counters) is far below the '
+                'algorithmic bytes the gathered table is cache resident and what limits the side is '
+                'instruction issue and the cache-to-CU gather rate (see limited_by per side)',
+        'kernel': 'half-sweep launch = max_abs + gram_chunks + sum_slabs + solve_rows '
+                  '(+ solve_rows_dual for short rows at padded rank 64 and 128), mean of user side and item side',
+        'bytes_per_launch': (b_user + b_item) / 2.0,
+        'ms_per_launch': t / 2.0 * 1e3,
+        'user_side': user, 'item_side': item,
+        'counters': ({k: v for k, v in counters.items()
+                      if k not in ('user_side', 'item_side')} if counters else None),
+    })
+    return out
+
+
+def rmse_gap(a, b):
+    """Largest relative difference between two per-sweep RMSE histories over their common
+    sweeps (both start from the same factors; entry j = the error after sweep j)."""
+    n = min(len(a), len(b))
+    pairs = [(x, y) for x, y in zip(a[:n], b[:n]) if x is not None and y is not None and y > 0]
+    return (max(abs(x - y) / y for x, y in pairs) if pairs else None), n
 
 
 def main():
@@ -340,28 +447,30 @@ def main():
     if world == 1 and args.dtype == 'float32' and args.config == 'c2' and not args.no_f64 and cuda:
         eng64 = make_engine('float64')
         e64, u64, i64, _, r64 = timed_sweeps(eng64, 5, 2, fused, barrier, cuda)
-        b64 = half_sweep_bytes(eng64.csr.nnz, eng64.csr.n_rows, eng64.kp, 8) + \
-            half_sweep_bytes(eng64.csc.nnz, eng64.csc.n_rows, eng64.kp, 8)
+        roof64 = roofline_report(eng64, 'float64', u64, i64, fused,
+                                 measured_counters(args.config, 'float64'))
+        gap, n_cmp = rmse_gap(rmse, r64)
         f64 = {'dtype': 'f64 (v_mfma_f64_16x16x4 Gram, block LDL^T solve on the accumulator tiles)',
                'ms_per_step': e64 / 5 * 1e3, 'sweeps_per_sec': 5 / e64,
+               'value': eng64.nnz * 5 / e64, 'unit': 'nnz/s',
                'user_ms': u64 * 1e3, 'item_ms': i64 * 1e3,
-               'roofline_frac': b64 / (u64 + i64) / 1e9 / HBM_PEAK_GBS,
-               'train_rmse_last': r64[-1] if r64 else None}
+               'roofline_frac': roof64['frac'], 'roofline_bound': roof64['bound'],
+               'roofline': {k: roof64[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac',
+                                                   'traffic', 'hbm_roof_ms_per_sweep',
+                                                   'matrix_roof_ms_per_sweep')},
+               'train_rmse': r64,
+               'rmse_fp32_vs_fp64_max_rel': gap, 'rmse_sweeps_compared': n_cmp}
         del eng64
 
     if rank_id == 0:
         s = 4 if args.dtype == 'float32' else 8
         kp = engine.kp
-        b_user = half_sweep_bytes(engine.csr.nnz, engine.csr.n_rows, kp, s)
-        if fused:
-            b_user += engine.csr.n_rows * kp * s  # the replaced vectors are read for the error
-        b_item = half_sweep_bytes(engine.csc.nnz, engine.csc.n_rows, kp, s)
         b_sse = sddmm_bytes(engine.csr.nnz, engine.csr.n_rows, kp, s)
-        achieved = (b_user + b_item) / (t_user + t_item) / 1e9
         counters = measured_counters(args.config, args.dtype) if world == 1 else None
-        traffic = None
-        if counters and 'user_side' in counters:
-            traffic = (counters['user_side']['hbm_bytes'] + counters['item_side']['hbm_bytes']) / 2
+        # a stand-in backend (ALSMI_BENCH_BACKEND, CPU rehearsals of the multi-rank logic) times no
+        # kernel: its line carries no roofline
+        roofline = roofline_report(engine, args.dtype, t_user, t_item, fused, counters) \
+            if plug is None else None
         sweeps_per_sec = args.steps / elapsed
         strong = bool(cfg['blocks'])
         line = {
@@ -382,28 +491,17 @@ def main():
             'config': {'workload': cfg['workload'], 'users': engine.n, 'items': engine.m,
                        'nnz': engine.nnz, 'rank': cfg['rank'], 'alpha': 0.1,
                        'parallelism': 'row-sharded x%d' % world},
-            'roofline': {
-                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'note': 'achieved = algorithmic bytes (uncached model: every stored entry '
-                        'fetches one factor row) / HIP-event time; where the measured HBM '
-                        'traffic is far below them the gathered table is cache resident and '
-                        'the side is bound by instruction issue (see the per-side entries)',
-                'kernel': 'half-sweep launch = max_abs + gram_chunks + sum_slabs + solve_rows '
-                          '(+ solve_rows_dual for short rows at padded rank 64 and 128), mean of user side and item side',
-                'bytes_per_launch': (b_user + b_item) / 2.0,
-                'ms_per_launch': (t_user + t_item) / 2.0 * 1e3,
-                'user_side': side_report(t_user, b_user, counters, 'user_side'),
-                'item_side': side_report(t_item, b_item, counters, 'item_side'),
-                'counters': ({k: v for k, v in counters.items()
-                              if k not in ('user_side', 'item_side')} if counters else None),
-            },
+            'roofline': roofline,
             'error_pass': ({'schedule': 'fused into the next user half-sweep; one standalone '
                                         'pass after the last timed sweep',
                             'standalone_ms': t_sse * 1e3,
                             'standalone_GBps': b_sse / t_sse / 1e9} if fused else
                            {'schedule': 'standalone pass after every sweep'}),
-            'train_rmse': {'first': rmse[0] if rmse else None, 'last': rmse[-1] if rmse else None},
+            'train_rmse': {'first': rmse[0] if rmse else None, 'last': rmse[-1] if rmse else None,
+                           'per_sweep': rmse,
+                           'note': 'entry j = training RMSE after j sweeps (entry 0: the initial '
+                                   'factors), each taken from the next user half-sweep\'s normal '
+                                   'equations, the last one from the standalone pass'},
             'setup_s': {'generate': t_gen},
             'backend': 'hip' if plug is None else 'stand-in ' + plug,
         }
@@ -416,6 +514,7 @@ def main():
                                  '(max over ranks)' % (len(engine.plans_u), len(engine.plans_i)))
         if f64:
             line['f64'] = f64
+            line['rmse_fp32_vs_fp64_max_rel'] = f64['rmse_fp32_vs_fp64_max_rel']
         if world == 1 and args.cpu_frac > 0 and cuda:
             threads = int(os.environ.get('OMP_NUM_THREADS', '0')) or min(16, os.cpu_count() or 1)
             try:

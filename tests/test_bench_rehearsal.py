@@ -69,5 +69,6 @@ def test_single_rank_bench_line_fields():
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
                 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
         assert key in line, key
-    assert line['roofline']['frac'] == line['roofline']['achieved'] / line['roofline']['peak']
+    # a stand-in backend identifies itself and reports no roofline (it times no kernel)
+    assert line['backend'].startswith('stand-in') and line['roofline'] is None
     assert 'workload' in line['config'] and line['vs_baseline'] is None
