@@ -1288,7 +1288,9 @@ struct PivotBlock {
                 t = __builtin_amdgcn_mfma_f32_4x4x1f32(m, rows[j], t, 0, 0, 0);
             }
             rt = __builtin_amdgcn_mfma_f32_4x4x1f32(m, rows[NV], rt, 0, 0, 0);
-            mfma_f32_fence<1>();
+            // (the step boundary stays a scheduling barrier; the wait states a matrix result
+            // needs before a cross-lane fetch reads it are the compiler's)
+            __builtin_amdgcn_sched_barrier(0);
             dv[rp] = (g == gp) ? inv : dv[rp];
         }
         if constexpr (SOLVE_ZPROD && K + 1 < NV) {
