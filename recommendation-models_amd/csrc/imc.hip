@@ -126,6 +126,142 @@ __global__ __launch_bounds__(256) void gemm_tiles_kernel(int M, int N, int NB, i
             }
 }
 
+constexpr int GEMM_U = 4;        // k steps per operand group (16 k: step u of lane group g = k0 + 4g + u)
+constexpr int GEMM_GK = 4 * GEMM_U;
+
+// Operand values of one whole group of 16 k (all of them inside the range): no bounds checks,
+// the row / column indices are already clamped to valid ones by the caller.
+template <typename T, bool TRANS_A, int TM, int TN>
+__device__ __forceinline__ void gemm_load_full(T (&a)[GEMM_U][TM], T (&b)[GEMM_U][TN],
+                                               const T *__restrict__ A, int64_t lda,
+                                               const T *__restrict__ B, int64_t ldb,
+                                               const int (&arow)[TM], const int (&bcol)[TN],
+                                               int64_t kg, bool a_vec) {
+    if (!TRANS_A && a_vec) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            T v4[4];
+            load_vec<T, 4>(v4, A + (int64_t)arow[tm] * lda + kg);
+#pragma unroll
+            for (int u = 0; u < GEMM_U; ++u) a[u][tm] = v4[u];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                a[u][tm] = TRANS_A ? A[(kg + u) * lda + arow[tm]]
+                                   : A[(int64_t)arow[tm] * lda + kg + u];
+    }
+#pragma unroll
+    for (int u = 0; u < GEMM_U; ++u)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b[u][tn] = B[(kg + u) * ldb + bcol[tn]];
+}
+
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_mma(typename Mfma<T>::acc_t (&acc)[TM][TN],
+                                         const T (&a)[GEMM_U][TM], const T (&b)[GEMM_U][TN]) {
+#pragma unroll
+    for (int u = 0; u < GEMM_U; ++u)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                acc[tm][tn] = Mfma<T>::mma(a[u][tm], b[u][tn], acc[tm][tn]);
+}
+
+// The same product with the operands buffered twice (fp64: the kernel runs two waves per SIMD
+// beside 64 accumulator registers, too few to hide the loads of a group behind the other
+// waves' matrix instructions; in fp32 five waves per SIMD do that better than a second buffer:
+// 145 against 196 us at 138 493 x 128 x 256).  Same accumulation order as gemm_tiles_kernel.
+template <typename T, bool TRANS_A, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_tiles_pipe_kernel(
+    int M, int N, int NB, int64_t K, const T *__restrict__ A, int64_t lda,
+    const T *__restrict__ B, int64_t ldb, T *__restrict__ C, int64_t ldc, int64_t slice_stride) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int blocks_n = (N + 16 * TN - 1) / (16 * TN);
+    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_blocks = (int64_t)((M + 16 * TM - 1) / (16 * TM)) * blocks_n;
+    if (blk >= n_blocks) return;
+    const int i0 = (int)(blk / blocks_n) * 16 * TM, j0 = (int)(blk % blocks_n) * 16 * TN;
+    const int64_t kslice = (K + gridDim.z - 1) / gridDim.z;
+    const int64_t kb = (int64_t)blockIdx.z * kslice;
+    const int64_t ke = kb + kslice < K ? kb + kslice : K;
+    typename Mfma<T>::acc_t acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = typename Mfma<T>::acc_t{0, 0, 0, 0};
+    // Rows of op(A) beyond M and columns of B beyond NB are read from the last valid row /
+    // column instead (an output element depends on its own row and column only; those rows are
+    // not stored and those columns are stored as zero), so the loop has no bounds checks.
+    int arow[TM], bcol[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) arow[tm] = min(i0 + 16 * tm + q, M - 1);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bcol[tn] = min(j0 + 16 * tn + q, NB - 1);
+    const bool a_vec = !TRANS_A && (lda % 4) == 0 && (reinterpret_cast<uintptr_t>(A) % (4 * sizeof(T))) == 0;
+    // Whole groups of 16 k with two operand buffers: the loads of the next group are issued
+    // before the matrix instructions of the current one, so a wave's memory latency runs under
+    // its own matrix work.  The groups are accumulated in k order whatever the buffering.
+    const int64_t n_full = ke > kb ? (ke - kb) / GEMM_GK : 0;
+    const int64_t kg0 = kb + 4 * g;
+    T a0[GEMM_U][TM], b0[GEMM_U][TN];
+    T a1[GEMM_U][TM], b1[GEMM_U][TN];
+    if (n_full > 0)
+        gemm_load_full<T, TRANS_A, TM, TN>(a0, b0, A, lda, B, ldb, arow, bcol, kg0, a_vec);
+    int64_t i = 0;
+#pragma unroll 1
+    for (; i + 2 <= n_full; i += 2) {
+        gemm_load_full<T, TRANS_A, TM, TN>(a1, b1, A, lda, B, ldb, arow, bcol,
+                                           kg0 + (i + 1) * GEMM_GK, a_vec);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm_mma<T, TM, TN>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        // (the group after the last whole one is read from the last whole one's place
+        // again and never multiplied)
+        const int64_t nxt = i + 2 < n_full ? i + 2 : n_full - 1;
+        gemm_load_full<T, TRANS_A, TM, TN>(a0, b0, A, lda, B, ldb, arow, bcol,
+                                           kg0 + nxt * GEMM_GK, a_vec);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm_mma<T, TM, TN>(acc, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (i < n_full) gemm_mma<T, TM, TN>(acc, a0, b0);  // an odd number of whole groups
+    // the slice's last, partial group: values beyond the slice's end are zero
+    const int64_t kt = kb + n_full * GEMM_GK;
+    if (kt < ke) {
+        const int64_t kg = kt + 4 * g;
+#pragma unroll
+        for (int u = 0; u < GEMM_U; ++u) {
+            const bool k_ok = kg + u < ke;
+            const int64_t kk = k_ok ? kg + u : ke - 1;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const T v = TRANS_A ? A[kk * lda + arow[tm]] : A[(int64_t)arow[tm] * lda + kk];
+                a0[u][tm] = k_ok ? v : T(0);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b0[u][tn] = B[kk * ldb + bcol[tn]];
+        }
+        gemm_mma<T, TM, TN>(acc, a0, b0);
+    }
+    T *Cz = C + (int64_t)blockIdx.z * slice_stride;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i_out = i0 + 16 * tm + Mfma<T>::crow(g, r);
+                const int jj = j0 + 16 * tn + q;
+                if (i_out < M && jj < N)
+                    Cz[(int64_t)i_out * ldc + jj] = jj < NB ? acc[tm][tn][r] : T(0);
+            }
+}
+
 // Launches gemm_tiles_kernel with the tile block that fits the shape (wide outputs 2 x 4 tiles
 // per wave, narrow ones fewer, so that no wave multiplies padding).
 template <typename T, bool TRANS_A>
@@ -136,9 +272,10 @@ static void launch_gemm(int M, int N, int NB, int64_t K, const T *A, int64_t lda
     do {                                                                                         \
         const int64_t blocks = (int64_t)((M + 16 * TM - 1) / (16 * TM)) *                        \
                                ((N + 16 * TN - 1) / (16 * TN));                                  \
-        hipLaunchKernelGGL((gemm_tiles_kernel<T, TRANS_A, TM, TN>),                              \
-                           dim3((unsigned)((blocks + 3) / 4), 1, (unsigned)ksplit), dim3(256), 0, \
-                           st, M, N, NB, K, A, lda, B, ldb, C, ldc, slice_stride);               \
+        auto kern = sizeof(T) == 8 ? gemm_tiles_pipe_kernel<T, TRANS_A, TM, TN>                  \
+                                   : gemm_tiles_kernel<T, TRANS_A, TM, TN>;                      \
+        hipLaunchKernelGGL(kern, dim3((unsigned)((blocks + 3) / 4), 1, (unsigned)ksplit),        \
+                           dim3(256), 0, st, M, N, NB, K, A, lda, B, ldb, C, ldc, slice_stride); \
     } while (0)
     const bool tall = M > 16;
     if (N > 32) {
