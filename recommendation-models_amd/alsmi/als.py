@@ -152,6 +152,61 @@ class ALS(BaseEstimator):
     def _fit_built(self, built, X, y):
         """The sweep loop on ratings in canonical form (src/als.py:143-171)."""
         csr, (n, m), item_avg, dev_pairs = built
+        engine = AlsEngine.from_global(csr[0], csr[1], csr[2], (n, m), self.rank,
+                                       self.alpha, dtype=self.dtype, group=_default_group())
+        self._sweep_loop(engine, item_avg)
+        if dev_pairs is not None and dev_pairs[0].numel() > 0:
+            # score(X, y) (src/als.py:169) on the triplets and factor tables still on the device
+            du, di, dy = dev_pairs
+            _, sse = dev.sddmm(self.rank, du, di, engine.U, engine.V, dy.to(engine.U.dtype),
+                               want_pred=False)
+            self.reconstruction_err_ = -float(np.sqrt(float(sse.cpu()[0]) / du.numel()))
+        elif X is None:
+            self.reconstruction_err_ = float('nan')  # fit_device_triplets without a sample
+        else:
+            self.reconstruction_err_ = self.score(X, y)
+        return self.user_feats, self.item_feats
+
+    def fit_sharded(self, users, items, y, shape):
+        """``fit`` when every rank of the initialised ``torch.distributed`` group holds only a
+        PART of the ratings (config-4-sized problems never exist on one rank): `users`, `items`,
+        `y` are this rank's share of the distinct stored (user, item, rating) triplets, host
+        arrays or tensors on the rank's GPU, zero ratings not allowed.  The ranks exchange the
+        entries so that each ends with the CSR slice of its user range and the CSC slice of its
+        item range (AlsEngine.from_shards), run the reference's loop (src/als.py:143-169) on
+        them and all end with the full ``user_feats`` / ``item_feats``.  ``data`` is not
+        materialised (``update_user`` / ``add_user`` need a fit through ``fit``);
+        ``reconstruction_err_`` is the score over all ranks' triplets."""
+        import torch
+        device = dev.require_gpu()
+        shape = tuple(int(v) for v in shape)
+        as_t = lambda a, dt: (a if torch.is_tensor(a) else
+                              torch.from_numpy(np.ascontiguousarray(a))).to(device=device, dtype=dt)
+        du, di, dy = as_t(users, torch.int64), as_t(items, torch.int64), as_t(y, torch.float64)
+        if dy.numel() and bool((dy == 0).any()):
+            raise ValueError('fit_sharded: zero ratings are not stored entries; drop them')
+        group = _default_group()
+        engine = AlsEngine.from_shards(du, di, dy, shape, self.rank, self.alpha, dtype=self.dtype,
+                                       group=group)
+        self._data, self._data_dev = None, None
+        self._sweep_loop(engine, engine.item_means().cpu().numpy())
+        _, sse = dev.sddmm(self.rank, du.to(torch.int32), di.to(torch.int32), engine.U, engine.V,
+                           dy.to(engine.U.dtype), want_pred=False) if du.numel() else (None, None)
+        tot = torch.zeros(2, dtype=torch.float64, device=device)
+        if du.numel():
+            tot[0], tot[1] = sse[0], float(du.numel())
+        if engine.collective:
+            import torch.distributed as dist
+            dist.all_reduce(tot, group=group)
+        tot = tot.cpu().numpy()
+        self.reconstruction_err_ = -float(np.sqrt(tot[0] / tot[1])) if tot[1] else float('nan')
+        return self
+
+    def _sweep_loop(self, engine, item_avg):
+        """Initial factors and the ``while diff > tol`` loop (src/als.py:143-169) on an engine
+        that holds the ratings; leaves ``user_feats``, ``item_feats``, ``rmse_history_``,
+        ``n_iter_`` and the device tables behind."""
+        n, m = engine.n, engine.m
         random_state = check_random_state(self.random_state)
 
         # initial factors: uniform random items with row 0 = mean rating of the
@@ -159,9 +214,6 @@ class ALS(BaseEstimator):
         self.item_feats = random_state.rand(self.rank, m)
         self.item_feats[0] = item_avg
         self.user_feats = np.zeros((self.rank, n))
-
-        engine = AlsEngine.from_global(csr[0], csr[1], csr[2], (n, m), self.rank,
-                                       self.alpha, dtype=self.dtype, group=_default_group())
         engine.set_factors(self.user_feats, self.item_feats)
         # The error of sweep s is produced by the user half of sweep s+1, which reads the
         # same ratings and item factors anyway; its new user rows stay parked until the
@@ -237,17 +289,6 @@ class ALS(BaseEstimator):
         self.shape_ = (n, m)
         # the device tables stay for predictions (dropped when the host factors change)
         self._remember_tables(engine.U, engine.V)
-        if dev_pairs is not None and dev_pairs[0].numel() > 0:
-            # score(X, y) (src/als.py:169) on the triplets and factor tables still on the device
-            du, di, dy = dev_pairs
-            _, sse = dev.sddmm(self.rank, du, di, engine.U, engine.V, dy.to(engine.U.dtype),
-                               want_pred=False)
-            self.reconstruction_err_ = -float(np.sqrt(float(sse.cpu()[0]) / du.numel()))
-        elif X is None:
-            self.reconstruction_err_ = float('nan')  # fit_device_triplets without a sample
-        else:
-            self.reconstruction_err_ = self.score(X, y)
-        return self.user_feats, self.item_feats
 
     # -------------------------------------------------------------- predict
     def _pair_predictions(self, users, items):

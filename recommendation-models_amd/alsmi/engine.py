@@ -198,6 +198,107 @@ class AlsEngine(object):
                    group=group, backend=backend, chunk=chunk, total_nnz=int(ptr_h[-1]),
                    user_slabs=user_slabs, item_slabs=item_slabs)
 
+    @classmethod
+    def from_shards(cls, users, items, vals, shape, rank, alpha, dtype=np.float64, group=None,
+                    backend=None, chunk=0, user_slabs=None, item_slabs=None):
+        """Every rank is given only a PART of the ratings: (users, items, vals) torch tensors
+        (int ids, any float type) on the device its collectives run on, the distinct stored
+        (user, item) pairs of the whole matrix split over the ranks in any way.  No rank ever
+        holds the whole matrix: the per-user and per-item entry counts are all-reduced, the row
+        ranges cut from them (balanced by entries, as from_global cuts them), every entry
+        travels once to the owner of its user and once to the owner of its item
+        (all-to-all), and each rank orders what it received into its CSR and CSC slices —
+        the sharded counterpart of the reference building one scipy matrix (src/als.py:137-142)
+        and converting it per item (src/als.py:268-280).  A pair that occurs twice (on one rank
+        or on two) is an error here: "the last write wins" has no meaning across ranks."""
+        backend = backend if backend is not None else LocalBackend()
+        n, m = int(shape[0]), int(shape[1])
+        users, items = users.to(torch.int64), items.to(torch.int64)
+        if not (users.numel() == items.numel() == vals.numel()):
+            raise ValueError('users, items and vals must have the same length')
+        if users.numel() and (int(users.min()) < 0 or int(users.max()) >= n or
+                              int(items.min()) < 0 or int(items.max()) >= m):
+            raise IndexError('index out of bounds for shape {}'.format((n, m)))
+        collective = bounce = False
+        world, me = 1, 0
+        if group is not None:
+            import torch.distributed as dist
+            world, me = dist.get_world_size(group), dist.get_rank(group)
+            collective = world > 1 or force_collectives()
+            # several ranks rehearsing on one GPU under gloo: the exchanges go through the host
+            bounce = users.is_cuda and dist.get_backend(group) == 'gloo'
+        work = users.device if not (collective and bounce) else torch.device('cpu')
+
+        def all_reduce(t):
+            if collective:
+                import torch.distributed as dist
+                t = t.to(work)
+                dist.all_reduce(t, group=group)
+            return t
+
+        def exchange(dest, cols):
+            """Rows with destination rank dest[k] (sorted by it) -> the rows this rank receives
+            from every rank, in sender order."""
+            if not collective:
+                return cols
+            import torch.distributed as dist
+            order = torch.argsort(dest, stable=True)
+            send = torch.bincount(dest, minlength=world).to(work)
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)
+            send_l, recv_l = send.cpu().tolist(), recv.cpu().tolist()
+            out = []
+            for c in cols:
+                src = c[order].to(work).contiguous()
+                dst = torch.empty(int(sum(recv_l)), dtype=c.dtype, device=work)
+                dist.all_to_all_single(dst, src, output_split_sizes=recv_l,
+                                       input_split_sizes=send_l, group=group)
+                out.append(dst.to(users.device))
+            return out
+
+        def cut(counts):
+            ptr = np.zeros(counts.numel() + 1, dtype=np.int64)
+            np.cumsum(counts.cpu().numpy(), out=ptr[1:])
+            return split_by_nnz(ptr, world)
+
+        ub = cut(all_reduce(torch.bincount(users, minlength=n)))
+        ib = cut(all_reduce(torch.bincount(items, minlength=m)))
+
+        def side(rows, cols, bounds, n_cols):
+            """This rank's slice of the row-major structure: the entries whose row lies in its
+            range, ordered by (row, column)."""
+            inner = torch.from_numpy(bounds[1:-1]).to(rows.device)
+            r, c, v = exchange(torch.bucketize(rows, inner, right=True), [rows, cols, vals])
+            lo, hi = int(bounds[me]), int(bounds[me + 1])
+            key, order = torch.sort((r - lo) * n_cols + c)
+            if key.numel() > 1 and bool((key[1:] == key[:-1]).any()):
+                raise ValueError('from_shards: a (user, item) pair is stored more than once')
+            ptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=rows.device)
+            torch.cumsum(torch.bincount(r - lo, minlength=hi - lo), 0, out=ptr[1:])
+            return ptr, (key % n_cols).to(torch.int32), v[order]
+
+        csr = side(users, items, ub, m)
+        csc = side(items, users, ib, n)
+        total = all_reduce(torch.tensor([users.numel()], dtype=torch.int64, device=users.device))
+        return cls(csr, csc, (n, m), rank, alpha, dtype=dtype, user_bounds=ub, item_bounds=ib,
+                   group=group, backend=backend, chunk=chunk, total_nnz=int(total.cpu()[0]),
+                   user_slabs=user_slabs, item_slabs=item_slabs)
+
+    def item_means(self):
+        """Mean stored rating of every item (0 for an unrated one) as a float64 [m] tensor on
+        every rank (src/als.py:144-148): segment sums over this rank's item-major slice, one
+        per item and in stored order, then the row gather of the half-sweeps."""
+        ptr = torch.from_numpy(self.csc.indptr_host).to(self.V.device)
+        table = torch.zeros((self.m, 1), dtype=torch.float64, device=self.V.device)
+        if self.csc.nnz:
+            sums = torch.segment_reduce(self.csc.vals.to(torch.float64), 'sum', offsets=ptr,
+                                        initial=0.0)
+            cnt = (ptr[1:] - ptr[:-1]).to(torch.float64)
+            table[self.ilo:self.ihi, 0] = torch.where(cnt > 0, sums / cnt.clamp_min(1),
+                                                       torch.zeros_like(sums))
+        self._all_gather_rows(table, self.item_bounds)
+        return table[:, 0]
+
     # ---- factors ------------------------------------------------------------
     def set_factors(self, user_feats, item_feats):
         """Host (rank, n) / (rank, m) arrays -> device tables."""

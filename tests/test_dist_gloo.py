@@ -112,6 +112,86 @@ def test_sharded_sweeps_match_single_process(tmp_path, world, case):
         assert o['ib'][0] == 0 and o['ib'][-1] == m and np.all(np.diff(o['ib']) >= 0)
 
 
+def shard_worker(rank_id, world, port, case, out_dir):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE),
+                                                  'recommendation-models_amd'), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from alsmi.engine import AlsEngine
+    from oracle_backend import OracleBackend
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank_id, world_size=world)
+    try:
+        seed, n, m, nnz, rank, extra = case
+        P = random_problem(seed, n, m, nnz, rank, **extra)
+        # this rank's share of the triplets: a shuffled deal, unrelated to the row ranges
+        owner = np.random.default_rng(seed).permutation(P['users'].size) % world
+        if world > 2:
+            owner[owner == world - 1] = 0       # with 3 ranks the last one brings nothing
+        deal = owner == rank_id
+        mine = [torch.from_numpy(np.ascontiguousarray(P[k][deal])) for k in
+                ('users', 'items', 'vals')]
+        eng = AlsEngine.from_shards(mine[0], mine[1], mine[2], (n, m), rank, 0.1,
+                                    group=dist.group.WORLD, backend=OracleBackend())
+        ref = AlsEngine.from_global(P['indptr'], P['indices'], P['vals'], (n, m), rank, 0.1,
+                                    group=dist.group.WORLD, backend=OracleBackend())
+        # the same row ranges and the same local slices as the cut of the whole matrix
+        assert np.array_equal(eng.user_bounds, ref.user_bounds)
+        assert np.array_equal(eng.item_bounds, ref.item_bounds)
+        assert eng.nnz == ref.nnz == int(P['indptr'][-1])
+        for a, b in ((eng.csr, ref.csr), (eng.csc, ref.csc)):
+            assert np.array_equal(a.indptr_host, b.indptr_host)
+            assert np.array_equal(a.indices_np, b.indices_np)
+            assert np.array_equal(a.vals_np, b.vals_np)
+        means = eng.item_means().numpy()
+        cnt = np.bincount(P['items'], minlength=m)
+        want = np.where(cnt > 0, np.bincount(P['items'], weights=P['vals'], minlength=m) /
+                        np.maximum(cnt, 1), 0.0)
+        np.testing.assert_allclose(means, want, rtol=1e-13)
+        eng.set_factors(np.zeros_like(P['U']), P['V'])
+        for _ in range(2):
+            eng.sweep()
+        uf, itf = eng.get_factors()
+        np.savez(os.path.join(out_dir, 'shard%d.npz' % rank_id), uf=uf, itf=itf,
+                 n_mine=int(deal.sum()))
+        # a pair stored twice (on two ranks) is refused by every rank that receives it
+        if world == 2:
+            dup = [torch.cat([t, t[:1]]) if rank_id == 0 else
+                   torch.from_numpy(np.ascontiguousarray(P[k][deal | ~deal][:0])) for t, k in
+                   zip(mine, ('users', 'items', 'vals'))]
+            if rank_id == 1:    # the other rank holds every entry once more
+                dup = [torch.from_numpy(np.ascontiguousarray(P[k])) for k in
+                       ('users', 'items', 'vals')]
+            try:
+                AlsEngine.from_shards(dup[0], dup[1], dup[2], (n, m), rank, 0.1,
+                                      group=dist.group.WORLD, backend=OracleBackend())
+                raised = False
+            except ValueError:
+                raised = True
+            flag = torch.tensor([int(raised)])
+            dist.all_reduce(flag)
+            assert int(flag[0]) >= 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_ingest_builds_the_same_slices(tmp_path, world):
+    case = CASES[1]
+    port = free_port()
+    mp.spawn(shard_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    seed, n, m, nnz, rank, extra = case
+    P = random_problem(seed, n, m, nnz, rank, **extra)
+    uf, itf, _ = reference_run(P, rank, 0.1, 2)
+    outs = [np.load(os.path.join(str(tmp_path), 'shard%d.npz' % r)) for r in range(world)]
+    assert sum(int(o['n_mine']) for o in outs) == P['users'].size
+    for o in outs:
+        np.testing.assert_allclose(o['uf'], uf, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(o['itf'], itf, rtol=1e-9, atol=1e-12)
+
+
 def test_split_by_nnz():
     from alsmi.engine import split_by_nnz
     indptr = np.array([0, 0, 10, 10, 11, 40, 40], dtype=np.int64)

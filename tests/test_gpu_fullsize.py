@@ -121,6 +121,31 @@ def test_whole_matrix_properties_fp32(problem):
     assert worst < 2e-5
 
 
+def test_sharded_ingest_at_full_size(problem):
+    """AlsEngine.from_shards on the 20 M triplets in shuffled order (one rank: no exchange, the
+    ordering and the pointer arrays are what is tested at this size) gives the generator's own
+    CSR and CSC bit for bit."""
+    torch, P = problem['torch'], problem['prob']
+    indptr, indices, vals = P['csr']
+    users = torch.repeat_interleave(torch.arange(N_USERS, device=indptr.device),
+                                    indptr[1:] - indptr[:-1])
+    g = torch.Generator(device=indptr.device)
+    g.manual_seed(1)
+    perm = torch.randperm(NNZ, generator=g, device=indptr.device)
+    eng = problem['AlsEngine'].from_shards(users[perm], indices[perm], vals[perm],
+                                           P['shape'], RANK, 0.1, dtype='float32')
+    assert eng.nnz == NNZ
+    for side, want in ((eng.csr, P['csr']), (eng.csc, P['csc'])):
+        assert np.array_equal(side.indptr_host, want[0].cpu().numpy())
+        assert torch.equal(side.indices, want[1]) and torch.equal(side.vals, want[2])
+    # the per-item means of the initial factors (src/als.py:144-148)
+    cptr, _, cvals = P['csc']
+    cnt = (cptr[1:] - cptr[:-1]).to(torch.float64)
+    sums = torch.segment_reduce(cvals.to(torch.float64), 'sum', offsets=cptr, initial=0.0)
+    want = torch.where(cnt > 0, sums / cnt.clamp_min(1), torch.zeros_like(sums))
+    assert torch.equal(eng.item_means(), want)
+
+
 # ---- one GPU's share of the 1 B-entry rank-128 configuration -------------------------------
 # 1.25 M users x 1 M items, 125 M entries, rank 128 (BASELINE config 4 cut over 8 GPUs), fp32.
 # Most rows here are shorter than the rank and take the neighbour-by-neighbour kernels (<= 32

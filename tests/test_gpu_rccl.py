@@ -112,3 +112,51 @@ def test_estimators_run_on_a_forced_one_rank_group(rccl_group):
     assert np.array_equal(a.user_feats, b.user_feats)
     assert np.array_equal(a.item_feats, b.item_feats)
     np.testing.assert_allclose(a.rmse_history_, b.rmse_history_, rtol=1e-12)
+
+
+def test_fit_sharded_equals_fit_on_rccl_and_without_a_group(rccl_group):
+    """ALS.fit_sharded (every rank brings a part of the triplets; the entries travel by
+    all-to-all to the owners of their user and of their item) against ALS.fit on the same
+    ratings: through the forced one-rank RCCL group, and with no group at all."""
+    import torch
+    import torch.distributed as dist
+    from alsmi import ALS
+    from alsmi import device as dev
+    from alsmi.engine import AlsEngine, default_group
+    device = dev.require_gpu()
+    rng = np.random.default_rng(8)
+    n, m, nnz = 900, 400, 30000
+    flat = rng.permutation(n * m)[:nnz]                  # distinct pairs in no particular order
+    users, items = flat // m, flat % m
+    vals = rng.integers(1, 11, nnz).astype(np.float64) / 2
+    ref = ALS(rank=12, random_state=4, max_iter=5, dtype='float64').fit((users, items), vals,
+                                                                        shape=(n, m))
+    assert default_group() is rccl_group and dist.get_backend(rccl_group) == 'nccl'
+    a = ALS(rank=12, random_state=4, max_iter=5, dtype='float64').fit_sharded(
+        users, items, vals, (n, m))
+    os.environ['ALSMI_FORCE_COLLECTIVES'] = '0'
+    try:
+        b = ALS(rank=12, random_state=4, max_iter=5, dtype='float64').fit_sharded(
+            torch.from_numpy(users).to(device), torch.from_numpy(items).to(device),
+            torch.from_numpy(vals).to(device), (n, m))
+    finally:
+        os.environ['ALSMI_FORCE_COLLECTIVES'] = '1'
+    for est in (a, b):
+        assert np.array_equal(est.user_feats, ref.user_feats)
+        assert np.array_equal(est.item_feats, ref.item_feats)
+        np.testing.assert_allclose(est.rmse_history_, ref.rmse_history_, rtol=1e-12)
+        np.testing.assert_allclose(est.reconstruction_err_, ref.reconstruction_err_, rtol=1e-12)
+        np.testing.assert_allclose(est._predict((users[:50], items[:50])),
+                                   ref._predict((users[:50], items[:50])), rtol=1e-13)
+    # the slices the exchange builds are those of the device CSR / CSC builders
+    eng = AlsEngine.from_shards(torch.from_numpy(users).to(device),
+                                torch.from_numpy(items).to(device),
+                                torch.from_numpy(vals).to(device), (n, m), 12, 0.1,
+                                group=rccl_group)
+    csr = dev.build_csr(users, items, vals, (n, m), np.float64, device)
+    csc = dev.csr_to_csc(csr[0], csr[1], csr[2], (n, m))
+    for side, want in ((eng.csr, csr), (eng.csc, csc)):
+        assert np.array_equal(side.indptr_host, want[0].cpu().numpy())
+        assert torch.equal(side.indices, want[1]) and torch.equal(side.vals, want[2])
+    with pytest.raises(ValueError):
+        ALS(rank=4, max_iter=1).fit_sharded(users[:10], items[:10], np.zeros(10), (n, m))
