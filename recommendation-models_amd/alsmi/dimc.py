@@ -116,6 +116,41 @@ class DirtyIMC(BaseEstimator):
         self.reconstruction_err_ = -root_mean_squared_error(r_, uv + xzy)
         return self.imc.Z, self.als.user_feats, self.als.item_feats
 
+    def fit_sharded(self, X, y, shape, Z=None):
+        """``fit`` when every rank of the initialised ``torch.distributed`` group holds only
+        its OWN samples (attribute form: X = (x one row per user, y_ one row per item, users,
+        items), y this rank's 1-D ratings, the distinct (user, item) pairs of the whole
+        problem split over the ranks in any way).  IMC on the union of the samples (each rank
+        evaluates its share, the p x q results are all-reduced), then ALS on the residual
+        r - x^T Z y (src/dimc.py:155-160), whose entries travel to the owners of their user and
+        item rows (ALS.fit_sharded); residuals that are exactly zero are not stored, as in the
+        reference's element-by-element fill.  ``reconstruction_err_`` is the score over all
+        ranks' samples."""
+        self.als = ALS(rank=self.rank, alpha=self.als_alpha, tol=self.tol,
+                       random_state=self.random_state, n_jobs=self.n_jobs,
+                       verbose=self.verbose)
+        self.imc = IMC(n_components=self.n_components, method=self.method,
+                       alpha=self.imc_alpha, verbose=self.verbose)
+        x, y_, users, items = _check_x(X, indices=True)
+        users, items = np.asarray(users).ravel(), np.asarray(items).ravel()
+        r_ = np.asarray(y, dtype=np.float64).ravel()
+        prob = self.imc.fit_sharded((x, y_), users, items, r_, Z=Z)
+        resid = r_ - prob.predict_samples(self.imc.Z)
+        keep = resid != 0
+        self.als.fit_sharded(users[keep], items[keep], resid[keep], shape)
+        # score(X, y) (src/dimc.py:161): r - (uv + xzy) = residual - uv over all ranks' samples
+        import torch
+        from . import device as dev
+        uv = self.als._pair_predictions(users, items)
+        tot = torch.tensor([float(((resid - uv) ** 2).sum()), float(r_.size)],
+                           dtype=torch.float64, device=dev.require_gpu())
+        if prob.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(tot, group=prob.group)
+        tot = tot.cpu().numpy()
+        self.reconstruction_err_ = -float(np.sqrt(tot[0] / tot[1])) if tot[1] else float('nan')
+        return self
+
     def predict(self, X):
         """uv + xzy for the given samples (src/dimc.py:164-186)."""
         check_is_fitted(self, ['imc', 'als'])

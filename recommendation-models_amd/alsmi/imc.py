@@ -102,6 +102,65 @@ class ImcProblem(object):
         self._place(indptr, items_g, ratings_g, X_attrs, ypad)
 
     @classmethod
+    def from_local_samples(cls, X_attrs, Y_attrs, users, items, ratings, dtype=np.float64,
+                           group=None):
+        """Every rank of `group` brings its OWN samples (any split of the samples over the
+        ranks; no rank sees the others') together with the attribute rows of the users and
+        items they refer to (the whole tables are accepted, only the referenced rows are
+        uploaded).  Cost, gradient and Hessian-vector product are sums over the samples, so
+        each rank evaluates its share and the p x q result and the scalar are all-reduced
+        (src/imc.py:43-96 on the union of the samples); predictions stay with the rank that
+        owns the sample, ``n_samples`` is the count over all ranks."""
+        self = cls.__new__(cls)
+        self._init_device()
+        self.group = group
+        if group is not None:
+            import torch.distributed as dist
+            if dist.get_world_size(group) == 1 and not force_collectives():
+                self.group = None
+        self.local = True
+        self.dtype = np.dtype(dtype)
+        X_attrs = np.atleast_2d(np.asarray(X_attrs, dtype=np.float64))
+        Y_attrs = np.atleast_2d(np.asarray(Y_attrs, dtype=np.float64))
+        users = np.asarray(users).ravel().astype(np.int64)
+        items = np.asarray(items).ravel().astype(np.int64)
+        ratings = np.asarray(ratings, dtype=np.float64).ravel()
+        if not (users.size == items.size == ratings.size):
+            raise ValueError('users, items and ratings must have the same length')
+        self.n_users, self.p = X_attrs.shape
+        self.n_items, self.q = Y_attrs.shape
+        if users.size and (users.min() < 0 or users.max() >= self.n_users or
+                           items.min() < 0 or items.max() >= self.n_items):
+            raise IndexError('sample index out of range')
+        self.ld = self._padded_width(self.q)
+        self.ratings_host = ratings
+        # this rank's users and items renumbered 0..; samples grouped by (local) user
+        uniq_u, lu = np.unique(users, return_inverse=True)
+        uniq_i, li = np.unique(items, return_inverse=True)
+        self.order = None if users.size < 2 or bool(np.all(lu[1:] >= lu[:-1])) else \
+            np.argsort(lu, kind='stable')
+        if self.order is not None:
+            lu, li, ratings = lu[self.order], li[self.order], ratings[self.order]
+        indptr = np.zeros(uniq_u.size + 1, dtype=np.int64)
+        np.cumsum(np.bincount(lu, minlength=uniq_u.size), out=indptr[1:])
+        self.n_local_users, self.n_local_samples = int(uniq_u.size), int(users.size)
+        self.ulo, self.uhi, self.slo, self.shi = 0, self.n_local_users, 0, self.n_local_samples
+        self._sample_bounds = np.array([0, self.n_local_samples], dtype=np.int64)
+        total = self._torch.tensor([float(users.size)], dtype=self._torch.float64,
+                                   device=self.device)
+        if self.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(total, group=self.group)
+        self.n_samples = int(total.cpu()[0])
+        Y_loc = Y_attrs[uniq_i]
+        if self.q != self.ld:
+            ypad = np.zeros((Y_loc.shape[0], self.ld))
+            ypad[:, :self.q] = Y_loc
+            Y_loc = ypad
+        self._place(indptr, li.astype(np.int32), ratings, X_attrs[uniq_u], Y_loc)
+        return self
+
+    @classmethod
     def from_device_csr(cls, indptr, items, ratings, X, Y, dtype=np.float64):
         """The samples as the CSR structure of the ratings, already on the device (torch
         tensors: indptr int64 [n_users+1], items int32, ratings, X [n_users x p],
@@ -193,9 +252,11 @@ class ImcProblem(object):
         # predictions: this rank fills its samples' slots of the full (grouped) vector, the
         # other ranks' slots arrive by the gather below
         # (a shard without a group leaves them zero: its caller adds the shards up)
+        local = getattr(self, 'local', False)  # predictions of this rank's own samples only
         alloc = torch.zeros if self.group is None and self.n_local_samples != self.n_samples \
             else torch.empty
-        pred = alloc(self.n_samples, dtype=self._td, device=self.device) if want_pred else None
+        pred = alloc(self.n_local_samples if local else self.n_samples, dtype=self._td,
+                     device=self.device) if want_pred else None
         r = self.ratings if ratings is None else ratings
         if self.n_local_users > 0 and self.n_local_samples > 0:
             local_pred = pred[self.slo:self.shi] if want_pred else None
@@ -205,7 +266,7 @@ class ImcProblem(object):
             for t in (out, sse):
                 if t is not None:
                     dist.all_reduce(t, group=self.group)
-            if pred is not None:
+            if pred is not None and not local:
                 # all-gather-v of the ranks' slices: one broadcast per owner straight into its
                 # slots (1/N of the vector each, where an all-reduce of a zero-filled vector
                 # moved all of it through every rank)
@@ -533,6 +594,17 @@ class IMC(BaseEstimator):
         sse = prob.sse(Z)
         self.reconstruction_err_ = float(np.sqrt(sse / prob.n_samples))
         return Z
+
+    def fit_sharded(self, X, users, items, ratings, Z=None):
+        """``fit`` when every rank of the initialised ``torch.distributed`` group holds only
+        its OWN samples: X = (X_attrs, Y_attrs) one row per user / item, `users`, `items`,
+        `ratings` this rank's samples in index form (ImcProblem.from_local_samples).  Every
+        rank ends with the same Z; ``reconstruction_err_`` is the RMSE over all ranks'
+        samples.  Returns the problem (its ``predict_samples(Z)`` gives this rank's x^T Z y)."""
+        x, y_ = _check_x(X)
+        prob = ImcProblem.from_local_samples(x, y_, users, items, ratings, group=default_group())
+        self._fit_on(prob, Z)
+        return prob
 
     def fit_transform(self, X, y, Z=None):
         """Learn Z for the given data and return it (src/imc.py:220-254)."""

@@ -239,6 +239,73 @@ def imc_worker(rank_id, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def imc_local_worker(rank_id, world, port, out_dir):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE),
+                                                  'recommendation-models_amd'), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import warnings
+    import torch.distributed as dist
+    import alsmi.imc as imc_mod
+    from oracle_backend import make_oracle_imc_problem
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank_id, world_size=world)
+    try:
+        Problem = make_oracle_imc_problem()
+        imc_mod.ImcProblem = Problem
+        X, Y, users, items, r, Z, S = imc_case()
+        # this rank's own samples: a shuffled deal (users end up split between ranks); with
+        # three ranks the last one brings none
+        owner = np.random.default_rng(3).permutation(r.size) % world
+        if world > 2:
+            owner[owner == world - 1] = 0
+        mine = owner == rank_id
+        prob = Problem.from_local_samples(X, Y, users[mine], items[mine], r[mine],
+                                          group=dist.group.WORLD)
+        assert prob.n_samples == r.size and prob.n_local_samples == int(mine.sum())
+        res = dict(cost=prob.cost(Z, 0.3), grad=prob.grad(Z, 0.3), hessp=prob.hessp(S, 0.3),
+                   z0=prob.init_z(), pred=prob.predict_samples(Z), mine=mine)
+        est = imc_mod.IMC(alpha=0.3)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            est.fit_sharded((X, Y), users[mine], items[mine], r[mine])
+        res.update(fit_Z=est.Z, fit_err=est.reconstruction_err_)
+        np.savez(os.path.join(out_dir, 'imcl%d.npz' % rank_id), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_imc_on_each_ranks_own_samples(tmp_path, world):
+    import warnings
+    from oracle import imc_oracle as io
+    port = free_port()
+    mp.spawn(imc_local_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    X, Y, users, items, r, Z, S = imc_case()
+    outs = [np.load(os.path.join(str(tmp_path), 'imcl%d.npz' % k)) for k in range(world)]
+    assert sum(int(o['mine'].sum()) for o in outs) == r.size
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fit_Z, _, _ = io.fit_imc(X[users], Y[items], r, alpha=0.3)
+    fit_err = io.imc_score(fit_Z, X[users], Y[items], r)
+    preds = io.preds_indexed(Z, X, Y, users, items)
+    for o in outs:
+        np.testing.assert_allclose(o['cost'], io.cost_indexed(Z, X, Y, users, items, r, 0.3),
+                                   rtol=1e-12)
+        np.testing.assert_allclose(o['grad'], io.grad_indexed(Z, X, Y, users, items, r, 0.3),
+                                   rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(o['hessp'], io.hessp_indexed(S, X, Y, users, items, 0.3),
+                                   rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(o['z0'], io.init_z(X, Y, users, items, r), rtol=1e-9,
+                                   atol=1e-12)
+        # a rank predicts its own samples, in the order it gave them
+        np.testing.assert_allclose(o['pred'], preds[o['mine']], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(o['fit_Z'], fit_Z, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(o['fit_err'], fit_err, rtol=1e-6)
+        assert np.array_equal(o['fit_Z'], outs[0]['fit_Z'])
+
+
 def imc_case():
     rng = np.random.default_rng(17)
     n, m, p, q, ns = 60, 45, 7, 19, 700

@@ -160,3 +160,37 @@ def test_fit_sharded_equals_fit_on_rccl_and_without_a_group(rccl_group):
         assert torch.equal(side.indices, want[1]) and torch.equal(side.vals, want[2])
     with pytest.raises(ValueError):
         ALS(rank=4, max_iter=1).fit_sharded(users[:10], items[:10], np.zeros(10), (n, m))
+
+
+def test_dimc_fit_sharded_equals_fit(rccl_group):
+    """DirtyIMC.fit_sharded (src/dimc.py:145-162 with every rank bringing its own samples:
+    IMC evaluations all-reduced, the residual's entries exchanged into the ALS row ranges)
+    against DirtyIMC.fit on the same samples, through the forced one-rank RCCL group."""
+    import warnings
+    from alsmi import DirtyIMC
+    rng = np.random.default_rng(21)
+    n, m, p, q, ns = 400, 300, 6, 9, 12000
+    flat = rng.permutation(n * m)[:ns]
+    users, items = flat // m, flat % m
+    X, Y = rng.standard_normal((n, p)), rng.standard_normal((m, q))
+    Zs = rng.standard_normal((p, q)) * 0.3
+    P8, Q8 = rng.standard_normal((n, 3)) * 0.5, rng.standard_normal((m, 3)) * 0.5
+    vals = np.einsum('ij,ij->i', X[users].dot(Zs), Y[items]) + \
+        np.einsum('ij,ij->i', P8[users], Q8[items]) + rng.standard_normal(ns) * 0.05
+    kw = dict(rank=4, tol=1e-4, random_state=3, imc_alpha=1e-6, als_alpha=0.05)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ref = DirtyIMC(**kw).fit((X, Y, users, items), vals, shape=(n, m))
+        got = DirtyIMC(**kw).fit_sharded((X, Y, users, items), vals, (n, m))
+    # (the IMC stage sums over the users in another slicing once the users without samples are
+    # dropped, so the optimiser's iterates agree to rounding, not bit for bit)
+    np.testing.assert_allclose(got.imc.Z, ref.imc.Z, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(got.imc.reconstruction_err_, ref.imc.reconstruction_err_, rtol=1e-8)
+    assert got.als.n_iter_ == ref.als.n_iter_
+    np.testing.assert_allclose(got.als.user_feats, ref.als.user_feats, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got.als.item_feats, ref.als.item_feats, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got.reconstruction_err_, ref.reconstruction_err_, rtol=1e-6)
+    sel = rng.choice(ns, 500, replace=False)
+    sub = (X, Y, users[sel], items[sel])
+    np.testing.assert_allclose(got.predict(sub), ref.predict(sub), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got.score(sub, vals[sel]), ref.score(sub, vals[sel]), rtol=1e-5)
