@@ -149,8 +149,7 @@ class ImcProblem(object):
         total = self._torch.tensor([float(users.size)], dtype=self._torch.float64,
                                    device=self.device)
         if self.group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(total, group=self.group)
+            self._all_reduce(total)
         self.n_samples = int(total.cpu()[0])
         Y_loc = Y_attrs[uniq_i]
         if self.q != self.ld:
@@ -229,6 +228,18 @@ class ImcProblem(object):
             dev._ptr(self.Y), dev._ptr(Md), dev._ptr(out), dev._ptr(local_pred),
             dev._ptr(sse), dev._ptr(self.workspace), dev._stream()), 'alsmi_imc_eval')
 
+    def _all_reduce(self, t):
+        """Sum of `t` over the ranks of the group, in place.  Several ranks rehearsing on one
+        GPU under gloo go through a host copy (gloo hangs on device buffers that are reduced
+        again and again, as the evaluation buffers are); RCCL reduces the device tensor."""
+        import torch.distributed as dist
+        if t.is_cuda and dist.get_backend(self.group) == 'gloo':
+            host = t.cpu()
+            dist.all_reduce(host, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, group=self.group)
+
     def _eval_dev(self, mode, M, want_out=True, want_sse=False, want_pred=False, ratings=None):
         """One evaluation, results left on the device: (out [p x q] or None, sse [1] fp64 or
         None, predictions of ALL samples in the grouped order or None); None for everything
@@ -265,16 +276,23 @@ class ImcProblem(object):
             import torch.distributed as dist
             for t in (out, sse):
                 if t is not None:
-                    dist.all_reduce(t, group=self.group)
+                    self._all_reduce(t)
             if pred is not None and not local:
                 # all-gather-v of the ranks' slices: one broadcast per owner straight into its
                 # slots (1/N of the vector each, where an all-reduce of a zero-filled vector
                 # moved all of it through every rank)
                 sb = self._sample_bounds
+                bounce = pred.is_cuda and dist.get_backend(self.group) == 'gloo'
                 for k in range(sb.size - 1):
                     if sb[k + 1] > sb[k]:
-                        dist.broadcast(pred[int(sb[k]):int(sb[k + 1])],
-                                       src=dist.get_global_rank(self.group, k), group=self.group)
+                        part = pred[int(sb[k]):int(sb[k + 1])]
+                        src = dist.get_global_rank(self.group, k)
+                        if bounce:   # (ranks rehearsing on one GPU under gloo: see _all_reduce)
+                            host = part.cpu()
+                            dist.broadcast(host, src=src, group=self.group)
+                            part.copy_(host)
+                        else:
+                            dist.broadcast(part, src=src, group=self.group)
         return out, sse, pred
 
     def _eval(self, mode, M, want_out=True, want_sse=False, want_pred=False, ratings=None):
@@ -365,7 +383,7 @@ class ImcProblem(object):
         if self.group is not None:
             import torch.distributed as dist
             for t in (gU, gV, sse):
-                dist.all_reduce(t, group=self.group)
+                self._all_reduce(t)
         return (float(sse.cpu()[0]), gU.to(torch.float64).cpu().numpy(),
                 gV.to(torch.float64).cpu().numpy())
 
