@@ -104,10 +104,11 @@ def matrix_roof_seconds(gram, solve, products, dtype):
 
 
 def kernel_source_sha():
-    """Hash of the kernel sources: counters measured on another build are not reported."""
+    """Hash of the half-sweep kernels' sources (and of their build recipe): counters measured
+    on another build of them are not reported."""
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, 'recommendation-models_amd', 'csrc', '*.h*'))):
-        h.update(open(path, 'rb').read())
+    for name in ('als_sweep.hip', 'alsmi_common.h', 'alsmi_common.hip', 'Makefile'):
+        h.update(open(os.path.join(ROOT, 'recommendation-models_amd', 'csrc', name), 'rb').read())
     return h.hexdigest()[:16]
 
 

@@ -25,9 +25,10 @@ N_SIMD = 1024  # 256 CUs x 4
 
 
 def source_sha():
+    """The same hash as bench.py's kernel_source_sha: the half-sweep kernels' sources."""
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(root, 'recommendation-models_amd', 'csrc', '*.h*'))):
-        h.update(open(path, 'rb').read())
+    for name in ('als_sweep.hip', 'alsmi_common.h', 'alsmi_common.hip', 'Makefile'):
+        h.update(open(os.path.join(root, 'recommendation-models_amd', 'csrc', name), 'rb').read())
     return h.hexdigest()[:16]
 
 
@@ -115,14 +116,68 @@ def collect(spec):
         r, c = roof[side], entry[side]
         r['hbm_measured_bytes'] = c['hbm_bytes']
         r['hbm_measured_GBps'] = c['hbm_bytes'] / (r['ms'] * 1e-3) / 1e9
+        r['hbm_measured_frac_of_peak'] = r['hbm_measured_GBps'] / 8000.0
         r['mfma_util'] = c['mfma_util']
-        r['bound'] = 'hbm' if c['hbm_bytes'] >= 0.5 * r['algorithmic_bytes'] else 'issue/l2'
+        r['limited_by'] = 'hbm' if c['hbm_bytes'] >= 0.5 * r['algorithmic_bytes'] else \
+            'instruction issue / cache gather (the gathered table is cache resident)'
     roof['traffic'] = (entry['user_side']['hbm_bytes'] + entry['item_side']['hbm_bytes']) / 2
     roof['counters'] = {'kernels': kern, 'file': 'profiles/%s_summary.json' % tag,
                         'measured': 'same gpurun call as this line (tools/profile_round.sh)'}
     with open(os.path.join(dst, stem + '.json'), 'w') as f:
         f.write(json.dumps(line) + '\n')
     return '%s/%s' % (config, dtype), entry
+
+
+def collect_imc(dtype):
+    """gpurun_out/<tag>_imc_c3_<dtype>/ (tools/profile_imc.sh) -> profiles/<tag>_bench_imc_c3[_f32]*
+    and the summary entry: per kernel of an evaluation the mean HBM bytes per launch (2 x
+    FETCH_SIZE + WRITE_SIZE), its average time and matrix-pipe utilisation."""
+    src = os.path.join(root, 'gpurun_out', '%s_imc_c3_%s' % (tag, dtype))
+    stem = '%s_bench_imc_c3%s' % (tag, '' if dtype == 'float64' else '_f32')
+    stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)[0]
+    shutil.copy(stats, os.path.join(dst, stem + '_kernel_stats.csv'))
+    per = defaultdict(lambda: defaultdict(list))
+    for name, out in (('pmc_fetch_size', 'fetch_size'), ('pmc_write_size', 'write_size'),
+                      ('pmc_sq_waves', 'sq_issue')):
+        rows = rows_of(src, name)
+        with open(os.path.join(dst, '%s_pmc_%s.csv' % (stem, out)), 'w', newline='') as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+        for r in rows:
+            per[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(
+                float(r['Counter_Value']))
+    mean = lambda v: sum(v) / len(v) if v else 0.0
+    kern = {}
+    for r in csv.DictReader(open(stats)):
+        name = r['Name'].split('(')[0].replace('void ', '')
+        if 'alsmi::' not in r['Name'] or name not in per:
+            continue
+        c = per[name]
+        cycles = mean(c['GRBM_GUI_ACTIVE']) / 8.0
+        kern[name] = {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3,
+                      'hbm_bytes': 2 * mean(c['FETCH_SIZE']) * 1024 + mean(c['WRITE_SIZE']) * 1024,
+                      'mfma_util': (mean(c['SQ_VALU_MFMA_BUSY_CYCLES']) / (cycles * N_SIMD))
+                      if cycles else None}
+        kern[name]['hbm_GBps'] = kern[name]['hbm_bytes'] / (kern[name]['avg_us'] * 1e-6) / 1e9
+    line = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
+    # per evaluation: one launch of each of these kernels
+    per_eval = sum(k['hbm_bytes'] for n, k in kern.items()
+                   if any(t in n for t in ('imc_rows', 'gemm_tiles', 'imc_borders',
+                                           'reduce_partials')))
+    line['counters'] = {'kernels': kern, 'hbm_measured_bytes_per_eval': per_eval,
+                        'hbm_measured_GBps': per_eval / (line['cost_grad']['ms'] * 1e-3) / 1e9,
+                        'note': 'measured HBM-side traffic (FETCH_SIZE x 2 + WRITE_SIZE, per launch, '
+                                'summed over the kernels of one evaluation) beside the algorithmic '
+                                'bytes: the item attribute table is cache resident, so the '
+                                'algorithmic rate is not an HBM rate',
+                        'file': 'profiles/%s_summary.json' % tag}
+    with open(os.path.join(dst, stem + '.json'), 'w') as f:
+        f.write(json.dumps(line) + '\n')
+    return 'imc_c3/%s' % dtype, {'kernels': kern, 'hbm_measured_bytes_per_eval': per_eval,
+                                 'algorithmic_bytes_per_eval': line['algorithmic_bytes_per_eval'],
+                                 'cost_grad_ms': line['cost_grad']['ms'],
+                                 'hessp_ms': line['hessp']['ms']}
 
 
 def main():
@@ -140,6 +195,12 @@ def main():
     })
     doc.setdefault('configs', {})
     for spec in sys.argv[2:]:
+        if spec.startswith('imc_c3'):
+            key, entry = collect_imc(spec.partition('/')[2] or 'float64')
+            doc['configs'][key] = entry
+            print(key, json.dumps({n: {k: v[k] for k in ('avg_us', 'hbm_bytes', 'mfma_util')}
+                                   for n, v in entry['kernels'].items()}))
+            continue
         key, entry = collect(spec)
         doc['configs'][key] = entry
         print(key, json.dumps({s: {k: entry[s][k] for k in ('hbm_bytes', 'mfma_util')}
