@@ -151,8 +151,16 @@ int alsmi_sddmm_noalloc(int dtype, int rank, int64_t n_pairs, const int32_t *use
  * item_factors[i]>, best first, ties broken by the smaller item id; items_out [n_sel x k]
  * int32, scores_out [n_sel x k] of dtype.  1 <= k <= min(1024, n_items), n_items <= 16 776 960.
  * workspace: at least
- * alsmi_topk_workspace_bytes(dtype, n_sel, n_items) bytes (the dense n_sel x n_items score
- * block: batch the users accordingly).  Deterministic.  Scores are ranked by their bit
+ * alsmi_topk_workspace_bytes(dtype, n_sel, n_items) bytes (room for the dense n_sel x n_items
+ * score block: batch the users accordingly).  From 8192 items on and for small k (about
+ * k <= n_items / 170) the block is not written: a strided sample of the item tiles gives every
+ * user a lower bound of its k-th best score, a pass over all items keeps only the scores at
+ * or above it, and those candidates are sorted; a user with more candidates than there are
+ * slots (many equal scores) switches the whole call back to the dense block, on the device,
+ * with the same result.  ALSMI_F32 scores are formed on the fp16 matrix cores from a scaled
+ * two-way fp16 split of both tables (scales from the largest |factor| of the selected users
+ * and of the items): fp32 accuracy, the same bits for the same pair of vectors within a
+ * call.  Deterministic.  Scores are ranked by their bit
  * pattern in the total order of IEEE 754: -0.0 ranks below +0.0 (they do not tie), and a NaN
  * score with a clear sign bit ranks above +infinity, i.e. first (one with the sign bit set
  * below -infinity, last); finite factor tables never produce one. */

@@ -96,6 +96,50 @@ __device__ __forceinline__ void load_vec(T (&v)[NV], const T *p) {
     }
 }
 
+// ---- fp32 products on the fp16 matrix cores: the scaled two-way split ---------------------------
+// Rounded to nearest, x*S = h + l with h = fp16(x*S) and l = fp16(x*S - h) leaves an error of
+// 2^-24 |x*S|, the precision of an fp32 value, provided l stays in fp16's normal range; S is a
+// power of two chosen per table so that max |x| * S lies in [2^13, 2^14).  Then
+// x*y*S*S' = hh' + hl' + lh' up to 2^-24: three 16-bit matrix instructions per product.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// S from the bit pattern of max |x| over the source table (0 for an all-zero table).
+__device__ __forceinline__ float split_scale(unsigned max_bits) {
+    int e = (int)(max_bits >> 23) - 127;  // floor(log2 max)
+    if (max_bits == 0u || (max_bits >> 23) == 255u) e = 13;
+    e = e < -40 ? -40 : (e > 40 ? 40 : e);
+    return __builtin_bit_cast(float, (unsigned)(127 + 13 - e) << 23);
+}
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Low part of the split of two values x0*s0, x1*s1 whose high parts are the halves of h:
+// fp16(x*s - h) by v_fma_mixlo/mixhi_f16, a fused multiply-add with fp32 and fp16 operands
+// rounded once to fp16: one instruction per element instead of the two of "convert h back,
+// subtract, round".  With s a power of two x*s - h is exactly representable in fp32 and both
+// ways give the same bits (tools/probe/mix_probe.hip).  The compiler selects these instructions
+// only here and there by itself, hence the inline assembly.  The wait states the compiler puts
+// between a vector instruction and a matrix instruction that reads its result do not cover
+// registers written by inline assembly (without them one row in some thousands came out
+// wrong): every caller runs split_fence() between its last split_low and the first matrix
+// instruction that reads the results.
+__device__ __forceinline__ f16x2 split_low(f16x2 h, float x0, float s0, float x1, float s1) {
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    unsigned out;
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%5 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(out)
+        : "v"(x0), "v"(s0), "v"(x1), "v"(s1), "v"(hb));
+    return __builtin_bit_cast(f16x2, out);
+}
+__device__ __forceinline__ void split_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3");  // two wait states are required; two more for margin
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -10,11 +10,27 @@
 //           image of the scores (histograms in LDS) finds the k-th largest score, the
 //           candidates at or above it are compacted in item order and the k winners are
 //           sorted by (score descending, item id ascending) in LDS.  Deterministic.
+// For small k and many items the score block is never written (it is 14.8 GB for 138 493 users
+// x 26 744 items, and writing and re-reading it was all of the time): the two kernels first
+// run on a strided SAMPLE of the item tiles only, whose k-th best score per user is a lower
+// bound of the user's true k-th best; a second pass over ALL items computes the same scores
+// (bit for bit: a score depends on its two vectors only) and keeps just the (item, score)
+// pairs at or above that bound — a few hundred candidates per user, which contain the top k
+// — and a small kernel sorts each user's candidates by (score descending, item ascending).
+// Should a user collect more candidates than there are slots (many equal scores, e.g. an
+// all-zero factor table), a flag on the device switches in the two-kernel form for the whole
+// call; the result is the same either way.
+#include <stdlib.h>
+
 #include "alsmi_common.h"
 
 namespace alsmi {
 
 constexpr int TOPK_MAX_K = 1024;
+constexpr int TOPK_CAND = 1024;         // candidates per user the final sort takes
+constexpr int TOPK_CHUNK_CAND = 32;     // candidate slots per user and wave (item range of a wave)
+constexpr int TOPK_SAMPLE_MIN = 1024;   // sampled items, at least
+constexpr int64_t TOPK_FILTER_MIN_ITEMS = 8192;
 
 // order-preserving map float/double -> unsigned (larger value, larger key)
 __device__ __forceinline__ unsigned key_of(float x) {
@@ -39,19 +55,83 @@ struct ScoreTile {
     static constexpr int UT = (KS * (int)sizeof(T) / 4) * 4 <= 128 ? 4 : 2;
 };
 
-template <typename T, int NV>
+template <typename T>
+struct KeyT;
+template <>
+struct KeyT<float> {
+    typedef unsigned type;
+    static constexpr int BITS = 32;
+};
+template <>
+struct KeyT<double> {
+    typedef unsigned long long type;
+    static constexpr int BITS = 64;
+};
+__device__ __forceinline__ float score_of(unsigned k) {  // inverse of key_of
+    return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ double score_of(unsigned long long k) {
+    return __builtin_bit_cast(double, (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k);
+}
+
+// Where the scores of topk_scores_kernel go.
+//  MODE 0: every score to the dense block scores[user * row_len + item] (row_len = n_items).
+//  MODE 1: the sampled tiles only: sampled tile j is item tile j * tile_stride (a whole tile),
+//          its scores go to scores[user * row_len + 16 j + q] (row_len = 16 x sampled tiles).
+//  MODE 2: all items; a score at or above the user's threshold (order of key_of) is appended
+//          to the user's candidate list, the rest is dropped.
+template <typename T>
+struct ScoreOut {
+    T *scores;
+    int64_t row_len, tile_stride;
+    const T *thresh;       // MODE 2: threshold of user u = thresh[u * thresh_stride]
+    int64_t thresh_stride;
+    // MODE 2: every wave owns TOPK_CHUNK_CAND slots per user for the item range it walks
+    // (wave w of the item direction: tiles [w itw, (w+1) itw)), so no atomics are needed:
+    int *count;            // [n_sel x n_wchunks] candidates found (may exceed the slots: overflow)
+    int32_t *cand_item;    // [n_sel x n_wchunks x TOPK_CHUNK_CAND]
+    T *cand_score;
+    int64_t n_wchunks;
+    const int *run_if;     // when not null: the launch does nothing unless *run_if != 0
+};
+
+// MODE 2 bookkeeping of one wave: cnt[t][r] = candidates found so far for the user of tile t,
+// register r of this lane's group (the same value in the 16 lanes of the group).  A hit takes
+// the next slot of its user's list for this wave: the slots of the hits of one instruction are
+// numbered by lane inside the group (ballot + population counts), so nothing is atomic and the
+// list is in item order.
+template <typename T>
+__device__ __forceinline__ void push_candidates(const ScoreOut<T> &o, bool hit, T val, int64_t item,
+                                                int64_t user, int64_t wchunk, int g, int q,
+                                                int &cnt) {
+    const unsigned long long m = __ballot(hit);
+    if (m == 0) return;  // (the same for the whole wave)
+    const unsigned rowm = (unsigned)(m >> (16 * g)) & 0xffffu;
+    const int slot = cnt + __popc(rowm & ((1u << q) - 1u));
+    if (hit && slot < TOPK_CHUNK_CAND) {
+        const int64_t at = (user * o.n_wchunks + wchunk) * TOPK_CHUNK_CAND + slot;
+        o.cand_item[at] = (int32_t)item;
+        o.cand_score[at] = val;
+    }
+    cnt += __popc(rowm);
+}
+
+template <typename T, int NV, int MODE>
 __global__ __launch_bounds__(256) void topk_scores_kernel(int n_sel, const int32_t *__restrict__ sel,
                                                           const T *__restrict__ U,
                                                           const T *__restrict__ V, int64_t n_items,
-                                                          T *__restrict__ scores, int itw) {
+                                                          ScoreOut<T> o, int itw) {
+    typedef typename KeyT<T>::type key_t;
     constexpr int KP = NV * 16;
     constexpr int KS = ScoreTile<T, NV>::KS;
     constexpr int UT = ScoreTile<T, NV>::UT;
+    if (o.run_if && *o.run_if == 0) return;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, q = lane & 15;
     const int wl = threadIdx.x >> 6;
     const int64_t user_base = (int64_t)blockIdx.x * (16 * UT);
-    const int64_t n_tiles = (n_items + 15) / 16;
+    // tiles this launch walks: all item tiles, or (MODE 1) the sampled ones
+    const int64_t n_tiles = MODE == 1 ? o.row_len / 16 : (n_items + 15) / 16;
     const int64_t tile_begin = ((int64_t)blockIdx.y * 4 + wl) * itw;
     if (tile_begin >= n_tiles) return;
     const int64_t tile_end = tile_begin + itw < n_tiles ? tile_begin + itw : n_tiles;
@@ -64,8 +144,22 @@ __global__ __launch_bounds__(256) void topk_scores_kernel(int n_sel, const int32
 #pragma unroll
         for (int c = 0; c < KS; c += 4) load_vec<T, 4>(*reinterpret_cast<T(*)[4]>(&a[t][c]), row + c);
     }
+    const int64_t wchunk = (int64_t)blockIdx.y * 4 + wl;
+    key_t kthr[MODE == 2 ? UT : 1][4];
+    int cnt[MODE == 2 ? UT : 1][4];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t user = user_base + 16 * t + Mfma<T>::crow(g, r);
+                user = user < n_sel ? user : n_sel - 1;
+                kthr[t][r] = key_of(o.thresh[user * o.thresh_stride]);
+                cnt[t][r] = 0;
+            }
+    }
     for (int64_t it = tile_begin; it < tile_end; ++it) {
-        const int64_t item = 16 * it + q;
+        const int64_t item = 16 * (MODE == 1 ? it * o.tile_stride : it) + q;
         const bool item_ok = item < n_items;
         const T *row = V + (item_ok ? item : n_items - 1) * KP + g * KS;
         T b[KS];
@@ -79,24 +173,189 @@ __global__ __launch_bounds__(256) void topk_scores_kernel(int n_sel, const int32
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t user = user_base + 16 * t + Mfma<T>::crow(g, r);
-                if (item_ok && user < n_sel) scores[user * n_items + item] = acc[r];
+                if (!(item_ok && user < n_sel)) continue;
+                if constexpr (MODE == 0) {
+                    o.scores[user * o.row_len + item] = acc[r];
+                } else if constexpr (MODE == 1) {
+                    o.scores[user * o.row_len + 16 * it + q] = acc[r];
+                }
             }
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t user = user_base + 16 * t + Mfma<T>::crow(g, r);
+                    const bool hit = item_ok && user < n_sel && key_of(acc[r]) >= kthr[t][r];
+                    push_candidates<T>(o, hit, acc[r], item, user, wchunk, g, q, cnt[t][r]);
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t user = user_base + 16 * t + Mfma<T>::crow(g, r);
+                if (q == 0 && user < n_sel) o.count[user * o.n_wchunks + wchunk] = cnt[t][r];
+            }
+    }
+}
+
+// Largest |x| over the given rows of a table (rows[] when not null, else rows 0 .. n_rows-1) as
+// the bit pattern of a non-negative float, combined into *out with atomicMax (zeroed by the
+// caller): the power-of-two scale of the fp16 split is taken from it.
+__global__ __launch_bounds__(256) void topk_max_abs_kernel(int64_t n_rows,
+                                                           const int32_t *__restrict__ rows,
+                                                           const float *__restrict__ table, int kp,
+                                                           unsigned *__restrict__ out) {
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    const int per_row = kp / 4;
+    const int64_t total = n_rows * per_row;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / per_row;
+        const int64_t src = rows ? (int64_t)rows[r] : r;
+        const vec_t v = reinterpret_cast<const vec_t *>(table + src * kp)[i - r * per_row];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)  // one atomic per block (they all go to one address)
+        atomicMax(out, __builtin_bit_cast(
+                           unsigned, fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+
+// fp32 scores on the fp16 matrix cores (the scaled two-way split of alsmi_common.h, as in the
+// half-sweep's Gram build): the fp32 matrix instruction runs at the vector rate, 16 times below
+// the 16-bit one, and the score product was all of this kernel's time.  Lane (g,q) holds
+// dimensions 32 s + 8 g .. + 7 of user q (A) / item q (B) for step s: one 32-byte load each, the
+// operand of v_mfma_f32_16x16x32_f16 as it stands once split; three instructions per step
+// (h l' + l h' + h h').  The accumulators hold S_u S_v times the score; both scales are powers of
+// two, so the product below is exact.  A score depends on its two vectors (and the two scales
+// of the call) only.
+template <int NV>
+struct ScoreTileF16 {
+    static constexpr int KP = NV * 16;
+    static constexpr int NS = (KP + 31) / 32;   // steps of 32 dimensions
+    static constexpr int UT = NS <= 2 ? 4 : 2;  // user tiles per wave (8 NS operand registers each)
+};
+
+template <int NS>
+__device__ __forceinline__ void split_row(const float *__restrict__ row, int kp, int g, float scale,
+                                          f16x8 (&h)[NS], f16x8 (&l)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (32 * s + 8 * g < kp) load_vec<float, 8>(x, row + 32 * s + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 xs = f32x2{x[j], x[j + 1]} * scale;
+            const f16x2 hh = __builtin_convertvector(xs, f16x2);
+            const f16x2 ll = split_low(hh, x[j], scale, x[j + 1], scale);
+            h[s][j] = hh[0];
+            h[s][j + 1] = hh[1];
+            l[s][j] = ll[0];
+            l[s][j + 1] = ll[1];
         }
     }
 }
 
-template <typename T>
-struct KeyT;
-template <>
-struct KeyT<float> {
-    typedef unsigned type;
-    static constexpr int BITS = 32;
-};
-template <>
-struct KeyT<double> {
-    typedef unsigned long long type;
-    static constexpr int BITS = 64;
-};
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void topk_scores_f16_kernel(int n_sel,
+                                                              const int32_t *__restrict__ sel,
+                                                              const float *__restrict__ U,
+                                                              const float *__restrict__ V,
+                                                              int64_t n_items, ScoreOut<float> o,
+                                                              int itw,
+                                                              const unsigned *__restrict__ max_bits) {
+    constexpr int KP = NV * 16;
+    constexpr int NS = ScoreTileF16<NV>::NS;
+    constexpr int UT = ScoreTileF16<NV>::UT;
+    if (o.run_if && *o.run_if == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, q = lane & 15;
+    const int wl = threadIdx.x >> 6;
+    const int64_t user_base = (int64_t)blockIdx.x * (16 * UT);
+    const int64_t n_tiles = MODE == 1 ? o.row_len / 16 : (n_items + 15) / 16;
+    const int64_t tile_begin = ((int64_t)blockIdx.y * 4 + wl) * itw;
+    if (tile_begin >= n_tiles) return;
+    const int64_t tile_end = tile_begin + itw < n_tiles ? tile_begin + itw : n_tiles;
+    const float su = split_scale(max_bits[0]), sv = split_scale(max_bits[1]);
+    const float unscale = 1.0f / (su * sv);
+    f16x8 ah[UT][NS], al[UT][NS];
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+        int64_t ui = user_base + 16 * t + q;
+        ui = ui < n_sel ? ui : n_sel - 1;  // (rows past the end are computed and not stored)
+        split_row<NS>(U + (int64_t)sel[ui] * KP, KP, g, su, ah[t], al[t]);
+    }
+    const int64_t wchunk = (int64_t)blockIdx.y * 4 + wl;
+    float thr[MODE == 2 ? UT : 1][4];
+    int cnt[MODE == 2 ? UT : 1][4];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t user = user_base + 16 * t + 4 * g + r;
+                user = user < n_sel ? user : n_sel - 1;
+                thr[t][r] = o.thresh[user * o.thresh_stride];
+                cnt[t][r] = 0;
+            }
+    }
+    for (int64_t it = tile_begin; it < tile_end; ++it) {
+        const int64_t item = 16 * (MODE == 1 ? it * o.tile_stride : it) + q;
+        const bool item_ok = item < n_items;
+        f16x8 bh[NS], bl[NS];
+        split_row<NS>(V + (item_ok ? item : n_items - 1) * KP, KP, g, sv, bh, bl);
+        split_fence();
+        Mfma<float>::acc_t acc[UT];
+#pragma unroll
+        for (int t = 0; t < UT; ++t) acc[t] = Mfma<float>::acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int t = 0; t < UT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][s], bl[s], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < UT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][s], bh[s], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < UT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][s], bh[s], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t user = user_base + 16 * t + 4 * g + r;
+                const float val = acc[t][r] * unscale;
+                if constexpr (MODE == 0) {
+                    if (item_ok && user < n_sel) o.scores[user * o.row_len + item] = val;
+                } else if constexpr (MODE == 1) {
+                    if (item_ok && user < n_sel) o.scores[user * o.row_len + 16 * it + q] = val;
+                } else {
+                    // "not below the threshold" in floating point keeps a superset of the
+                    // scores whose key is at or above the threshold's (-0.0 beside +0.0, NaNs)
+                    const bool hit = !(val < thr[t][r]) && item_ok && user < n_sel;
+                    push_candidates<float>(o, hit, val, item, user, wchunk, g, q, cnt[t][r]);
+                }
+            }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t user = user_base + 16 * t + 4 * g + r;
+                if (q == 0 && user < n_sel) o.count[user * o.n_wchunks + wchunk] = cnt[t][r];
+            }
+    }
+}
 
 // Every thread's share of a row, eight independent loads at a time (one load per loop turn left
 // the passes waiting for a cache round trip per element); f(key, item index) per element.
@@ -122,8 +381,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void topk_select_kernel(const T *__restrict__ scores,
                                                           int64_t n_items, int k,
                                                           int32_t *__restrict__ out_idx,
-                                                          T *__restrict__ out_score) {
+                                                          T *__restrict__ out_score,
+                                                          const int *__restrict__ run_if) {
     typedef typename KeyT<T>::type key_t;
+    if (run_if && *run_if == 0) return;  // (the same for the whole launch)
     __shared__ unsigned hist[256];
     __shared__ key_t prefix_sh;
     __shared__ int want_sh, n_eq_sh;
@@ -254,23 +515,202 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const T *__restrict__ 
     }
 }
 
+// One workgroup per user: the user's candidates (the lists its waves of the score pass left,
+// TOPK_CAND in all at most) sorted by (score descending, item id ascending) in LDS, the first k
+// written out.  A list longer than its slots, or more candidates than the sort takes, raises
+// *overflow (the caller then redoes the call in the two-kernel form); such a user writes nothing.
+template <typename T>
+__global__ __launch_bounds__(256) void topk_candidates_kernel(const int *__restrict__ count,
+                                                              const int32_t *__restrict__ cand_item,
+                                                              const T *__restrict__ cand_score,
+                                                              int64_t n_wchunks, int k,
+                                                              int32_t *__restrict__ out_idx,
+                                                              T *__restrict__ out_score,
+                                                              int *__restrict__ overflow) {
+    typedef typename KeyT<T>::type key_t;
+    __shared__ key_t ckey[TOPK_CAND];
+    __shared__ int32_t cidx[TOPK_CAND];
+    __shared__ int n_sh, bad_sh;
+    const int tid = threadIdx.x;
+    const int64_t u = blockIdx.x;
+    if (tid == 0) {
+        n_sh = 0;
+        bad_sh = 0;
+    }
+    __syncthreads();
+    for (int64_t w = tid; w < n_wchunks; w += 256) {
+        const int c = count[u * n_wchunks + w];
+        if (c == 0) continue;
+        if (c > TOPK_CHUNK_CAND) {
+            bad_sh = 1;
+            continue;
+        }
+        const int at = atomicAdd(&n_sh, c);
+        if (at + c > TOPK_CAND) {
+            bad_sh = 1;
+            continue;
+        }
+        const int64_t from = (u * n_wchunks + w) * TOPK_CHUNK_CAND;
+        for (int i = 0; i < c; ++i) {
+            ckey[at + i] = key_of(cand_score[from + i]);
+            cidx[at + i] = cand_item[from + i];
+        }
+    }
+    __syncthreads();
+    if (bad_sh) {
+        if (tid == 0) atomicOr(overflow, 1);
+        return;
+    }
+    const int n = n_sh;
+    int np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + tid; i < np2; i += 256) {
+        ckey[i] = (key_t)0;
+        cidx[i] = INT32_MAX;
+    }
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < np2 / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const bool lo_better = ckey[lo] > ckey[hi] ||
+                                       (ckey[lo] == ckey[hi] && cidx[lo] < cidx[hi]);
+                if (lo_better != up) {
+                    const key_t tk = ckey[lo];
+                    ckey[lo] = ckey[hi];
+                    ckey[hi] = tk;
+                    const int32_t ti = cidx[lo];
+                    cidx[lo] = cidx[hi];
+                    cidx[hi] = ti;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k; i += 256) {
+        out_idx[u * k + i] = cidx[i];
+        out_score[u * k + i] = score_of(ckey[i]);
+    }
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Users per wave of the score kernel of (T, NV).
+template <typename T, int NV>
+constexpr int score_users_per_wave() {
+    if constexpr (sizeof(T) == 4) return 16 * ScoreTileF16<NV>::UT;
+    else return 16 * ScoreTile<T, NV>::UT;
+}
+
+template <typename T, int NV, int MODE>
+static void launch_scores(dim3 grid, hipStream_t st, int n_sel, const int32_t *sel, const T *U,
+                          const T *V, int64_t n_items, const ScoreOut<T> &o, int itw,
+                          const unsigned *max_bits) {
+    if constexpr (sizeof(T) == 4)
+        hipLaunchKernelGGL((topk_scores_f16_kernel<NV, MODE>), grid, dim3(256), 0, st, n_sel, sel, U,
+                           V, n_items, o, itw, max_bits);
+    else
+        hipLaunchKernelGGL((topk_scores_kernel<T, NV, MODE>), grid, dim3(256), 0, st, n_sel, sel, U,
+                           V, n_items, o, itw);
+}
+
+// Sampled item tiles of the filtered form for this (k, n_items), or 0 when the two-kernel form
+// is used: the expected number of candidates per user is k * n_items / sampled items, held to a
+// third of the slots; the sample must stay below half of the items to be worth its pass.
+static int64_t topk_sample_tiles(int64_t n_items, int k) {
+    if (n_items < TOPK_FILTER_MIN_ITEMS) return 0;
+    int64_t sample = (3 * (int64_t)k * n_items + TOPK_CAND - 1) / TOPK_CAND;
+    if (sample < TOPK_SAMPLE_MIN) sample = TOPK_SAMPLE_MIN;
+    if (sample < 4 * (int64_t)k) sample = 4 * (int64_t)k;
+    const int64_t tiles = (sample + 15) / 16, full_tiles = n_items / 16;
+    return 2 * tiles <= full_tiles ? tiles : 0;
+}
+
 template <typename T, int NV>
 static int run_topk(int n_sel, const int32_t *sel, const void *U, const void *V, int64_t n_items,
                     int k, int32_t *out_idx, void *out_score, void *workspace, hipStream_t st) {
     T *scores = static_cast<T *>(workspace);
+    const T *Ut = static_cast<const T *>(U), *Vt = static_cast<const T *>(V);
+    T *out_s = static_cast<T *>(out_score);
     // item tiles per wave: long walks when there are many user blocks to fill the chip with,
     // short ones for a handful of users
-    const int64_t user_blocks = (n_sel + 16 * ScoreTile<T, NV>::UT - 1) / (16 * ScoreTile<T, NV>::UT);
+    constexpr int UPW = score_users_per_wave<T, NV>();
+    const int64_t user_blocks = (n_sel + UPW - 1) / UPW;
     const int64_t n_tiles = (n_items + 15) / 16;
     const int itw = user_blocks >= 64 ? 32 : 4;
     const int64_t chunks = (n_tiles + 4 * itw - 1) / (4 * itw);
     ALSMI_REQUIRE(chunks <= 65535, "alsmi_topk_items: too many items (%lld)", (long long)n_items);
-    hipLaunchKernelGGL((topk_scores_kernel<T, NV>), dim3((unsigned)user_blocks, (unsigned)chunks),
-                       dim3(256), 0, st, n_sel, sel, static_cast<const T *>(U),
-                       static_cast<const T *>(V), n_items, scores, itw);
+    const dim3 grid_all((unsigned)user_blocks, (unsigned)chunks);
+    const size_t block_bytes = (size_t)n_sel * (size_t)n_items * sizeof(T);
+    // behind the dense block the workspace has 256 spare bytes: the overflow flag of the
+    // filtered form and (fp32) the largest |factor| of the selected users and of the items
+    char *tail = static_cast<char *>(workspace) + align_up(block_bytes, 16);
+    unsigned *max_bits = reinterpret_cast<unsigned *>(tail + 16);
+    if constexpr (sizeof(T) == 4) {
+        ALSMI_HIP_CHECK(hipMemsetAsync(max_bits, 0, 2 * sizeof(unsigned), st));
+        const int kp = NV * 16;
+        auto blocks_for = [&](int64_t rows) {
+            const int64_t b = (rows * (kp / 4) + 255) / 256;
+            return (unsigned)(b < 1 ? 1 : (b > 512 ? 512 : b));
+        };
+        hipLaunchKernelGGL(topk_max_abs_kernel, dim3(blocks_for(n_sel)), dim3(256), 0, st,
+                           (int64_t)n_sel, sel, reinterpret_cast<const float *>(Ut), kp, max_bits);
+        hipLaunchKernelGGL(topk_max_abs_kernel, dim3(blocks_for(n_items)), dim3(256), 0, st, n_items,
+                           (const int32_t *)nullptr, reinterpret_cast<const float *>(Vt), kp,
+                           max_bits + 1);
+        ALSMI_HIP_CHECK(hipGetLastError());
+    }
+
+    // ---- filtered form (see the head of the file) -------------------------------------------
+    const int *flag = nullptr;
+    static const bool filter_on = !(getenv("ALSMI_TOPK_FILTER") && atoi(getenv("ALSMI_TOPK_FILTER")) == 0);
+    const int64_t s_tiles = filter_on ? topk_sample_tiles(n_items, k) : 0;
+    // buffers inside the dense block's memory: sampled scores | counts | candidate items | scores
+    const int64_t n_wchunks = (n_tiles + itw - 1) / itw;  // waves of the item direction with work
+    const size_t off_count = align_up((size_t)n_sel * s_tiles * 16 * sizeof(T), 256);
+    const size_t off_item = off_count + align_up((size_t)n_sel * n_wchunks * sizeof(int), 256);
+    const size_t off_score = off_item + align_up((size_t)n_sel * n_wchunks * TOPK_CHUNK_CAND *
+                                                 sizeof(int32_t), 256);
+    const size_t need = off_score + (size_t)n_sel * n_wchunks * TOPK_CHUNK_CAND * sizeof(T);
+    if (s_tiles > 0 && need <= block_bytes) {
+        char *base = static_cast<char *>(workspace);
+        int *flag_w = reinterpret_cast<int *>(tail);
+        int *count = reinterpret_cast<int *>(base + off_count);
+        ALSMI_HIP_CHECK(hipMemsetAsync(flag_w, 0, sizeof(int), st));
+        ScoreOut<T> o = {};
+        o.scores = scores;
+        o.row_len = s_tiles * 16;
+        o.tile_stride = (n_items / 16) / s_tiles;
+        const int64_t s_chunks = (s_tiles + 4 * itw - 1) / (4 * itw);
+        launch_scores<T, NV, 1>(dim3((unsigned)user_blocks, (unsigned)s_chunks), st, n_sel, sel, Ut,
+                                Vt, n_items, o, itw, max_bits);
+        ALSMI_HIP_CHECK(hipGetLastError());
+        // the k best of the sample, best first: out_s[u * k + k - 1] is the user's threshold
+        hipLaunchKernelGGL((topk_select_kernel<T>), dim3(n_sel), dim3(256), 0, st, scores,
+                           (int64_t)(s_tiles * 16), k, out_idx, out_s, (const int *)nullptr);
+        ALSMI_HIP_CHECK(hipGetLastError());
+        o.thresh = out_s + (k - 1);
+        o.thresh_stride = k;
+        o.count = count;
+        o.cand_item = reinterpret_cast<int32_t *>(base + off_item);
+        o.cand_score = reinterpret_cast<T *>(base + off_score);
+        o.n_wchunks = n_wchunks;
+        launch_scores<T, NV, 2>(grid_all, st, n_sel, sel, Ut, Vt, n_items, o, itw, max_bits);
+        ALSMI_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL((topk_candidates_kernel<T>), dim3(n_sel), dim3(256), 0, st, count,
+                           o.cand_item, o.cand_score, n_wchunks, k, out_idx, out_s, flag_w);
+        ALSMI_HIP_CHECK(hipGetLastError());
+        flag = flag_w;  // the two kernels below run only if a user overflowed its slots
+    }
+    ScoreOut<T> all = {};
+    all.scores = scores;
+    all.row_len = n_items;
+    all.run_if = flag;
+    launch_scores<T, NV, 0>(grid_all, st, n_sel, sel, Ut, Vt, n_items, all, itw, max_bits);
     ALSMI_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL((topk_select_kernel<T>), dim3(n_sel), dim3(256), 0, st, scores, n_items, k,
-                       out_idx, static_cast<T *>(out_score));
+                       out_idx, out_s, flag);
     ALSMI_HIP_CHECK(hipGetLastError());
     return ALSMI_OK;
 }

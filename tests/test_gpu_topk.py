@@ -147,3 +147,59 @@ def test_topk_ties_across_the_kth_score(dtype, k):
     Vc = dev.factors_to_device(np.tile(base[:, None], (1, m)), dtype, device)
     items, _ = dev.topk_items(rank, torch.from_numpy(users[:3]).to(device), Ud, Vc, k)
     np.testing.assert_array_equal(items.cpu().numpy(), np.tile(np.arange(k), (3, 1)))
+
+
+@pytest.mark.parametrize('dtype,rank,m,k', [('float32', 64, 20000, 10), ('float64', 10, 9001, 25),
+                                             ('float32', 128, 12345, 1), ('float64', 64, 8200, 3)])
+def test_topk_filtered_form_matches_dense_ranking(dtype, rank, m, k):
+    """Item counts from 8192 on with a small k take the form that never writes the score block
+    (threshold from a sample of the item tiles, candidates at or above it, sort): the same
+    checks as for the two-kernel form, groups of identical items around the k-th score
+    included, plus a table whose scores are ALL equal — every item is then a candidate, the
+    slots overflow and the call must fall back to the two-kernel form on the device."""
+    import torch
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    device = dev.require_gpu()
+    rng = np.random.default_rng(rank + m + k)
+    n = 150
+    U = rng.standard_normal((rank, n))
+    V = rng.standard_normal((rank, m))
+    V[:, m - 1] = V[:, 7]                      # exact ties, one of them in the last (partial) tile
+    V[:, 4000:4040] = V[:, [11]]               # forty identical items
+    Ud = dev.factors_to_device(U, dtype, device)
+    Vd = dev.factors_to_device(V, dtype, device)
+    users = rng.permutation(n)[:97].astype(np.int32)
+    items, scores = dev.topk_items(rank, torch.from_numpy(users).to(device), Ud, Vd, k)
+    items, scores = items.cpu().numpy().astype(np.int64), scores.to(torch.float64).cpu().numpy()
+    Uq, Vq = dev.factors_to_host(Ud, rank), dev.factors_to_host(Vd, rank)
+    want_items, want_scores = ao.topk_items(Uq, Vq, users, k)
+    tol = 1e-12 if dtype == 'float64' else 2e-5
+    np.testing.assert_allclose(scores, want_scores, rtol=tol, atol=tol)
+    differ = items != want_items
+    assert np.abs(scores[differ] - want_scores[differ]).max(initial=0) < (1e-12 if dtype == 'float64' else 5e-5)
+    assert (np.diff(scores, axis=1) <= 0).all()
+    tie = np.diff(scores, axis=1) == 0
+    assert (np.diff(items, axis=1)[tie] > 0).all()
+    assert all(np.unique(r).size == k for r in items)
+    dense = Uq[:, users].T.dot(Vq)
+    np.testing.assert_allclose(np.take_along_axis(dense, items, axis=1), scores, rtol=tol, atol=2e-5)
+    for r in range(users.size):
+        rest = np.delete(dense[r], items[r])
+        assert rest.max() <= scores[r, -1] + (1e-12 if dtype == 'float64' else 5e-5)
+    # users whose best items are the forty identical ones: the smallest ids of the group first
+    best_is_group = np.flatnonzero((items[:, 0] >= 4000) & (items[:, 0] < 4040))
+    for r in best_is_group:
+        run = items[r][scores[r] == scores[r, 0]]
+        np.testing.assert_array_equal(run, (np.r_[11, 4000:4040] if 11 < 4000 else [])[:run.size])
+    # all scores equal (and a second, two-valued table): slot overflow -> the fallback
+    base = rng.standard_normal(rank)
+    Vc = dev.factors_to_device(np.tile(base[:, None], (1, m)), dtype, device)
+    it2, sc2 = dev.topk_items(rank, torch.from_numpy(users[:5]).to(device), Ud, Vc, k)
+    np.testing.assert_array_equal(it2.cpu().numpy(), np.tile(np.arange(k), (5, 1)))
+    assert (sc2 == sc2[:, :1]).all()
+    # the same users, batched differently (another workspace limit), give the same lists
+    again, sc_again = dev.topk_items(rank, torch.from_numpy(users).to(device), Ud, Vd, k,
+                                     max_workspace_bytes=m * 8 * 33)
+    np.testing.assert_array_equal(again.cpu().numpy(), items)
+    np.testing.assert_array_equal(sc_again.to(torch.float64).cpu().numpy(), scores)
