@@ -1198,6 +1198,10 @@ __device__ unsigned long long g_phase[8];
 #define SOLVE_ZPROD 1
 #endif
 
+#ifndef DUAL_TR16_MIN
+#define DUAL_TR16_MIN 5
+#endif
+
 // Lane constants of the block solver.
 struct SolveLane {
     int lane, g, q, irow, addr_row, addr_col;
@@ -1418,7 +1422,7 @@ __device__ __forceinline__ bool block_solve(Gram<float, NV> &G, int lane, int ra
     for (int e = 0; e < NV; ++e) y[e] = col_allreduce(G.b[e]);
     // The neighbour systems of short rows keep the fp32 instruction: their solve is a small part
     // of their kernels and the split's registers would cost them a wave per SIMD.
-    constexpr bool TR16 = !DUAL && NV > 1;
+    constexpr bool TR16 = (!DUAL || NV >= DUAL_TR16_MIN) && NV > 1;
     if constexpr (TR16) {
         // largest diagonal element of the real unknowns -> [2^27, 2^28) (see split_tile above)
         float dmax = 0.0f;
@@ -1955,8 +1959,13 @@ struct SolveArgs {
 };
 
 // Rows of at most this many entries are solved in the neighbour-by-neighbour ("dual") form
-// when the padded rank is larger (fp32: up to 64 entries at padded rank 128, up to 48 at 64).
-constexpr int DUAL_MAX_DEG = 64;
+// when the padded rank is larger (fp32: up to 96 entries at padded rank 128, up to 48 at 64),
+// in classes of 16: class k holds the rows of at most DUAL_MAX_DEG - 16 k entries.
+#ifndef DUAL_MAX_DEG_128
+#define DUAL_MAX_DEG_128 96
+#endif
+constexpr int DUAL_MAX_DEG = DUAL_MAX_DEG_128;
+constexpr int DUAL_CLASSES = DUAL_MAX_DEG / 16;
 
 // LDS elements one wave needs: the small transposition stage on the fast path (padded rank
 // <= 64, no dump), the whole matrix otherwise.
@@ -2212,7 +2221,8 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
     constexpr int KP = NV * 16;
     constexpr int NC = KP / 32;  // 32-dimension chunks, one matrix instruction deep each
     constexpr bool KEEP = dual_keep(NV, ND, ERR);
-    static_assert(KP % 32 == 0 && ND * 16 <= WAVE, "one index block per row");
+    static_assert(KP % 32 == 0 && ND * 16 <= 2 * WAVE, "at most two entries per lane");
+    constexpr bool TWO = ND > 4;  // rows of more than 64 entries: a second entry per lane
     const int lane = threadIdx.x & 63;
     const int wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = gridDim.x * 4;
@@ -2237,11 +2247,18 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
         const int64_t at = beg + (lane_v < n ? lane_v : 0);
         const int idx = p.indices[at];
         const float rv = lane_v < n ? p.vals[at] : 0.0f;
+        int idx_hi = 0;
+        float rv_hi = 0.0f;
+        if constexpr (TWO) {
+            const int64_t at_hi = beg + (lane_v + WAVE < n ? lane_v + WAVE : 0);
+            idx_hi = p.indices[at_hi];
+            rv_hi = lane_v + WAVE < n ? p.vals[at_hi] : 0.0f;
+        }
         int id[ND];
         bool real[ND];
 #pragma unroll
         for (int a = 0; a < ND; ++a) {
-            id[a] = __builtin_amdgcn_ds_bpermute(4 * (16 * a + q), idx);
+            id[a] = __builtin_amdgcn_ds_bpermute(4 * (16 * (a & 3) + q), a < 4 ? idx : idx_hi);
             real[a] = 16 * a + q < n;
         }
         const float *srcg = p.src + 8 * g;
@@ -2316,7 +2333,7 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
         // right-hand side S^2 r, one neighbour per column; block_solve adds the four lane groups
 #pragma unroll
         for (int a = 0; a < ND; ++a) {
-            const float ra = bperm(4 * (16 * a + q), rv);
+            const float ra = bperm(4 * (16 * (a & 3) + q), a < 4 ? rv : rv_hi);
             G.b[a] = g == 0 ? ra * s2 : 0.0f;
         }
         float w[ND];
@@ -2440,7 +2457,7 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
         if constexpr (ERR && !(DUAL_ABLATE & 4)) {
 #pragma unroll
             for (int a = 0; a < ND; ++a) {
-                const float ra = bperm(4 * (16 * a + q), rv);
+                const float ra = bperm(4 * (16 * (a & 3) + q), a < 4 ? rv : rv_hi);
                 const float pa = col_allreduce(pred[a]);
                 const double e = (double)ra - (double)pa;
                 err_acc += (g == 0 && real[a]) ? e * e : 0.0;
@@ -2469,9 +2486,10 @@ struct alsmi_plan {
     int dtype, rank, kp, chunk, device, cu_count;
     int64_t n_rows_total, row_begin, row_end;
     int n_tasks, n_chunks, n_heavy;
-    // Tasks [t_dual[k], t_dual[k+1]) have at most 16 (4 - k) entries (and more than 16 (3 - k));
-    // t_dual[4] = n_tasks, and all five = n_tasks when the dual form does not apply to the plan.
-    int t_dual[5];
+    // Tasks [t_dual[k], t_dual[k+1]) have at most DUAL_MAX_DEG - 16 k entries (and more than
+    // DUAL_MAX_DEG - 16 (k + 1)); the last = n_tasks, and all = n_tasks when the dual form does
+    // not apply to the plan.
+    int t_dual[alsmi::DUAL_CLASSES + 1];
     int solve_prio;  // bit 0: the plan's rows are short on average (see solve_rows_kernel);
                      // bit 1: the short-row kernels raise their priority too (always, -1 %)
     int32_t *order, *slab_first, *slab_count;
@@ -2688,18 +2706,31 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     n_err += used;
     if constexpr (sizeof(T) == 4 && (NV == 8 || NV == 4)) {
         if (dual) {
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < DUAL_CLASSES; ++k) {
                 a.err_part = pl->err_part + n_err;
                 a.t_begin = pl->t_dual[k];
                 a.t_end = pl->t_dual[k + 1];
-                switch (k) {
-                    case 0:  // (a 64 x 64 neighbour system gains nothing at padded rank 64)
+                used = 0;
+                // (a neighbour system of 64 or more gains nothing at padded rank 64: its classes
+                // are empty there, see alsmi_plan_create)
+                switch (DUAL_CLASSES - k) {
+#if DUAL_MAX_DEG_128 >= 96
+                    case 6:
+                        if constexpr (NV == 8)
+                            rc = launch_dual<NV, 6>(pl, a, err_out != nullptr, &used, st);
+                        break;
+#endif
+#if DUAL_MAX_DEG_128 >= 80
+                    case 5:
+                        if constexpr (NV == 8)
+                            rc = launch_dual<NV, 5>(pl, a, err_out != nullptr, &used, st);
+                        break;
+#endif
+                    case 4:
                         if constexpr (NV == 8)
                             rc = launch_dual<NV, 4>(pl, a, err_out != nullptr, &used, st);
-                        else
-                            used = 0;
                         break;
-                    case 1: rc = launch_dual<NV, 3>(pl, a, err_out != nullptr, &used, st); break;
+                    case 3: rc = launch_dual<NV, 3>(pl, a, err_out != nullptr, &used, st); break;
                     case 2: rc = launch_dual<NV, 2>(pl, a, err_out != nullptr, &used, st); break;
                     default: rc = launch_dual<NV, 1>(pl, a, err_out != nullptr, &used, st); break;
                 }
@@ -2810,19 +2841,19 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     pl->n_tasks = (int)n;
     pl->n_chunks = (int)ch_beg.size();
     pl->n_heavy = n_heavy;
-    for (int k = 0; k < 5; ++k) pl->t_dual[k] = (int)n;
+    for (int k = 0; k <= alsmi::DUAL_CLASSES; ++k) pl->t_dual[k] = (int)n;
     {
         const int64_t entries = indptr_host[row_end] - indptr_host[row_begin];
         static const int forced = getenv("ALSMI_SOLVE_PRIO") ? atoi(getenv("ALSMI_SOLVE_PRIO")) : -1;
         pl->solve_prio = forced >= 0 ? forced : ((n > 0 && entries / n <= SOLVE_PRIO_MAX_MEAN ? 1 : 0) | 2);
     }
     if (dtype == ALSMI_F32 && (kp == 128 || kp == 64)) {
-        // The n x n form is used for rows of at most 48 (padded rank 64) / 64 (128) entries AND
+        // The n x n form is used for rows of at most 48 (padded rank 64) / 96 (128) entries AND
         // at most `rank` entries: with more entries than dimensions F F^T is rank deficient, its
         // condition number is that of the ridge alone, and fp32 loses rows the rank x rank
         // form solves easily (found at rank 33 with rows of 34 to 48 entries).
         const int64_t dual_max = std::min<int64_t>(kp == 64 ? 48 : alsmi::DUAL_MAX_DEG, rank);
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < alsmi::DUAL_CLASSES; ++k) {
             const int64_t deg = std::min<int64_t>(alsmi::DUAL_MAX_DEG - 16 * k, dual_max);
             pl->t_dual[k] = (int)(std::partition_point(order.begin(), order.end(), [&](int32_t r) {
                                       return indptr_host[r + 1] - indptr_host[r] > deg;
@@ -2850,7 +2881,8 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     pl->err_part_cap = pl->cu_count * 64;
     if (e == hipSuccess)
         e = upload((void **)&pl->err_part, nullptr,
-                   5 * (size_t)pl->err_part_cap * sizeof(double));  // up to five kernels per call
+                   (alsmi::DUAL_CLASSES + 1) * (size_t)pl->err_part_cap *
+                       sizeof(double));  // one share per kernel of a call
     if (e != hipSuccess) {
         set_error("alsmi_plan_create: device allocation failed: %s", hipGetErrorString(e));
         alsmi_plan_destroy(pl);

@@ -192,9 +192,9 @@ def test_rank128_slice_sampled_rows_match_oracle():
                                     threads=1)[0]
         err = row_rel_err(got, want)
         d = deg[rows]
-        # every kernel is in the sample: <= 32 and <= 64 entries (neighbour form), up to one
-        # chunk (rank form) and the chunked rows
-        for lo, hi in ((1, 32), (33, 64), (65, 2048)):
+        # every kernel is in the sample: <= 32, <= 64 and <= 96 entries (neighbour form), up to
+        # one chunk (rank form) and the chunked rows
+        for lo, hi in ((1, 32), (33, 64), (65, 96), (97, 2048)):
             assert ((d >= lo) & (d <= hi)).any(), (lo, hi)
         assert err.max() < 1e-4, (err.max(), d[np.argmax(err)])
         return d
