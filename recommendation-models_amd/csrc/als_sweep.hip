@@ -2512,7 +2512,8 @@ static size_t slab_slots(int kp) {
 // priority (ALSMI_SOLVE_PRIO=0..3 overrides: bit 0 the ld x ld kernel, bit 1 the short-row kernels).
 constexpr int64_t SOLVE_PRIO_MAX_MEAN = 384;
 
-// Diagnostic build selected by the environment (fp32, padded rank 64, plain half-sweep only).
+// Diagnostic build selected by the environment (fp32, padded rank 64 — and 128 for the values
+// 1 and 2 —, plain half-sweep only).
 static int ablation() {
     static const int v = getenv("ALSMI_ABLATE") ? atoi(getenv("ALSMI_ABLATE")) : 0;
     return v;
@@ -2562,6 +2563,13 @@ static int launch_solve(const alsmi_plan *pl, SolveArgs<T> a, bool dump, bool wa
         if (wide && !dump)
             kern = want_err ? solve_rows_kernel<T, NV, WPB, false, 20, true>
                             : solve_rows_kernel<T, NV, WPB, false, 20, false>;
+    }
+    if constexpr (sizeof(T) == 4 && NV == 8) {  // (accumulate-only / solve-only timing builds)
+        const int ablate = ablation();
+        if (!dump && !want_err && !wide) {
+            if (ablate == 1) kern = solve_rows_kernel<T, NV, WPB, false, 1>;
+            if (ablate == 2) kern = solve_rows_kernel<T, NV, WPB, false, 2>;
+        }
     }
     if constexpr (sizeof(T) == 4 && NV == 4) {
         const int ablate = ablation();
