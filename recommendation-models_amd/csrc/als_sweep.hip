@@ -935,6 +935,20 @@ __device__ __forceinline__ void add_ridge_dual(Gram<float, ND> &G, int lane, int
         }
 }
 
+template <int ND>
+__device__ __forceinline__ void add_ridge_dual_d(Gram<double, ND> &G, int lane, int n_real,
+                                                 double ridge) {
+    const int g = lane >> 4, q = lane & 15;
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool diag = Mfma<double>::crow(g, r) == q;
+            const double add = (16 * a + q < n_real) ? ridge : 1.0;
+            G.acc[tri_index(a, a, ND)][r] += diag ? add : 0.0;
+        }
+}
+
 // Accumulator tiles -> one matrix row per lane, NV passes of 16 columns each through the
 // stage.  Pass f moves the columns {c*NV + f}: tiles (e,f) with e <= f are stored as they are,
 // tiles with e > f come from tile (f,e) by symmetry.  a[] ends up in natural column order.
@@ -1842,13 +1856,18 @@ struct BackBlockD {
 
 // Solves the NV*16 system held in G (ridge not yet added); xc[k] of lane (.,q) is the solution
 // component of dimension q*NV + k.  False when a pivot is not positive or the result not finite.
-template <int NV>
+// DUAL: the unknowns are the neighbours of a short row (block a = neighbours 16a .. 16a+15, the
+// first `rank` of them real), see solve_rows_dual_d_kernel.
+template <int NV, bool DUAL = false>
 __device__ __forceinline__ bool block_solve_d(Gram<double, NV> &G, int lane, int rank, double ridge,
                                               double (&xc)[NV], double *stash,
                                               long long *pc = nullptr) {
     asm volatile("" : "+v"(lane));
     PHASE_T(ta);
-    add_ridge<double, NV>(G, lane, rank, ridge);
+    if constexpr (DUAL)
+        add_ridge_dual_d<NV>(G, lane, rank, ridge);
+    else
+        add_ridge<double, NV>(G, lane, rank, ridge);
     double y[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) y[e] = col_allreduce_d(G.b[e]);
@@ -2478,6 +2497,170 @@ __global__ __launch_bounds__(256, dual_min_waves(NV, ND, ERR)) void solve_rows_d
     }
 }
 
+// ---- kernel 2c: short rows in the neighbour-by-neighbour form, fp64 ------------------------------
+// The same identity as in solve_rows_dual_kernel, on the fp64 matrix pipe: K = F F^T is formed
+// by v_mfma_f64_16x16x4, whose operand is one double per lane (lane (g,q): row q, contraction
+// slot g).  The contraction runs over the factor dimensions in any order, so lane group g takes
+// dimensions 16c + 4g .. + 3 of chunk c, one per step: a lane's 32-byte load of one neighbour is
+// four steps' operands as it stands.  w = (K + c I)^-1 r comes from the fp64 block solver, and
+// x = F^T w from a second pass over the neighbours' rows (cache hits), summed over a lane
+// group's 16 lanes.  At padded rank 128 the n x n system saves most where the rank x rank one
+// costs most: the fp64 solve of 128 unknowns is as long as the Gram build of 120 entries.
+// Waves per SIMD: the 21 tiles of 96 neighbours take the registers of a whole SIMD (and four
+// such waves' back-substitution data 96 KB of LDS); 80 neighbours fit twice (-29 % measured).
+#ifndef DUAL_D_ABLATE
+#define DUAL_D_ABLATE 0  // timing builds only: 1 no solve, 2 no x = F^T w pass, 4 no matrix instructions
+#endif
+constexpr int dual_d_min_waves(int nd) { return nd >= 6 ? 1 : (nd >= 3 ? 2 : 3); }
+template <int NV, int ND, bool ERR>
+__global__ __launch_bounds__(256, dual_d_min_waves(ND)) void solve_rows_dual_d_kernel(
+    SolveArgs<double> p) {
+    constexpr int KP = NV * 16;
+    constexpr int NC = KP / 16;   // 16-dimension chunks, four matrix instructions deep each
+    constexpr bool TWO = ND > 4;  // rows of more than 64 entries: a second entry per lane
+    static_assert(ND * 16 <= 2 * WAVE, "at most two entries per lane");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the pivot blocks' back-substitution data (block_solve_d)
+    double *stash = reinterpret_cast<double *>(smem) + (size_t)wl * (ND * 8 * WAVE);
+    const int W = gridDim.x * 4;
+    double err_acc = 0.0;
+    for (int t = p.t_begin + blockIdx.x * 4 + wl; t < p.t_end; t += W) {
+        const int row = p.order[t];
+        const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
+        const int n = (int)(end - beg);
+        double *out = p.dst + (int64_t)row * KP;
+        if (n <= 0) {
+#pragma unroll
+            for (int rr = 0; rr < KP / 64; ++rr) out[lane + 64 * rr] = 0.0;
+            continue;
+        }
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));  // lane constants derived per row, not kept across rows
+        const int g = lane_v >> 4, q = lane_v & 15;
+        // lanes past the row's end repeat its first entry (their rows of F are zeroed below)
+        const int64_t at = beg + (lane_v < n ? lane_v : 0);
+        const int idx = p.indices[at];
+        const double rv = lane_v < n ? p.vals[at] : 0.0;
+        int idx_hi = 0;
+        double rv_hi = 0.0;
+        if constexpr (TWO) {
+            const int64_t at_hi = beg + (lane_v + WAVE < n ? lane_v + WAVE : 0);
+            idx_hi = p.indices[at_hi];
+            rv_hi = lane_v + WAVE < n ? p.vals[at_hi] : 0.0;
+        }
+        int id[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+            id[a] = __builtin_amdgcn_ds_bpermute(4 * (16 * (a & 3) + q), a < 4 ? idx : idx_hi);
+        // (instantiation ND only sees rows of more than 16 (ND - 1) entries: all tiles but the
+        // last are full)
+        const bool last_real = 16 * (ND - 1) + q < n;
+        const double *srcg = p.src + 4 * g;
+        Gram<double, ND> G;
+        G.zero();
+        double pred[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) pred[a] = 0.0;
+#pragma unroll 2
+        for (int c = 0; c < NC; ++c) {
+            double v[ND][4];
+#pragma unroll
+            for (int a = 0; a < ND; ++a)
+                load_vec<double, 4>(v[a], srcg + ((int64_t)id[a] * KP + 16 * c));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[ND - 1][s] = last_real ? v[ND - 1][s] : 0.0;
+            if constexpr (ERR) {
+                // <current vector, neighbour> rides along (the current vector may live in the
+                // table being written: it is read before the row's stores)
+                double uc[4];
+                load_vec<double, 4>(uc, p.cur + ((int64_t)row * KP + 16 * c) + 4 * g);
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) pred[a] += v[a][s] * uc[s];
+            }
+#if DUAL_D_ABLATE & 4
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+                    G.acc[tri_index(a, a, ND)][s] += v[a][s];
+#else
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < ND; ++a)
+#pragma unroll
+                    for (int b = a; b < ND; ++b)
+                        G.acc[tri_index(a, b, ND)] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                            v[a][s], v[b][s], G.acc[tri_index(a, b, ND)], 0, 0, 0);
+#endif
+        }
+        // right-hand side r, one neighbour per column; block_solve_d adds the four lane groups
+        double ra[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            ra[a] = shfl_d(a < 4 ? rv : rv_hi, 16 * (a & 3) + q);
+            G.b[a] = g == 0 ? ra[a] : 0.0;
+        }
+        double w[ND];
+#if DUAL_D_ABLATE & 1
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            double tt = G.b[a];
+#pragma unroll
+            for (int b = a; b < ND; ++b)
+                for (int r = 0; r < 4; ++r) tt += G.acc[tri_index(a, b, ND)][r];
+            w[a] = tt;
+        }
+#else
+        const bool ok = block_solve_d<ND, true>(G, lane, n, p.alpha * (double)n, w, stash);
+#endif
+        if constexpr (ERR) {
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+                const double pa = col_allreduce_d(pred[a]);
+                const double e = ra[a] - pa;
+                err_acc += (g == 0 && 16 * a + q < n) ? e * e : 0.0;
+            }
+        }
+        // x = F^T w: the neighbours' rows again, this lane's four dimensions of each chunk,
+        // summed over the 16 lanes of the lane group; lane q = 0 of each group stores them
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+            asm volatile("" : "+v"(id[a]));  // re-read, do not keep the first pass's registers
+            w[a] = (ok && 16 * a + q < n) ? w[a] : 0.0;
+        }
+#if DUAL_D_ABLATE & 2
+        if (q == 0) out[4 * g] = w[0] + w[ND - 1];
+#else
+#pragma unroll 2
+        for (int c = 0; c < NC; ++c) {
+            double v[ND][4];
+#pragma unroll
+            for (int a = 0; a < ND; ++a)
+                load_vec<double, 4>(v[a], srcg + ((int64_t)id[a] * KP + 16 * c));
+            f64x4 x;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double acc = 0.0;
+#pragma unroll
+                for (int a = 0; a < ND; ++a) acc += v[a][s] * w[a];
+                x[s] = row_allreduce_d(acc);
+            }
+            if (q == 0) *reinterpret_cast<f64x4 *>(out + 16 * c + 4 * g) = x;
+        }
+#endif
+    }
+    if constexpr (ERR) {
+        const double wave_err = wave_sum(err_acc);
+        if (lane == 0) p.err_part[blockIdx.x * 4 + wl] = wave_err;
+    }
+}
+
 }  // namespace alsmi
 
 // ---- plan ------------------------------------------------------------------------------------
@@ -2524,6 +2707,12 @@ static int ablation() {
 static bool dual_enabled() {
     static const bool v = !(getenv("ALSMI_DUAL") && atoi(getenv("ALSMI_DUAL")) == 0);
     return v;
+}
+
+// ALSMI_DUAL_F64=0: the same for fp64 alone.
+static bool dual_f64_enabled() {
+    static const bool v = !(getenv("ALSMI_DUAL_F64") && atoi(getenv("ALSMI_DUAL_F64")) == 0);
+    return v && dual_enabled();
 }
 
 // Does an fp32 source table of n_src rows need 64-bit gather addresses?  ALSMI_WIDE=1 forces
@@ -2618,6 +2807,28 @@ static int launch_dual(const alsmi_plan *pl, SolveArgs<float> a, bool want_err, 
     return ALSMI_OK;
 }
 
+template <int NV, int ND>
+static int launch_dual_d(const alsmi_plan *pl, SolveArgs<double> a, bool want_err, int *n_err,
+                         hipStream_t st) {
+    *n_err = 0;
+    const int n_tasks = a.t_end - a.t_begin;
+    if (n_tasks <= 0) return ALSMI_OK;
+    auto kern = want_err ? solve_rows_dual_d_kernel<NV, ND, true>
+                         : solve_rows_dual_d_kernel<NV, ND, false>;
+    const size_t lds = (size_t)4 * ND * 8 * WAVE * sizeof(double);
+    ALSMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int grid = 0;
+    int rc = resident_grid(pl, reinterpret_cast<const void *>(kern), 256, lds, n_tasks, 4, &grid);
+    if (rc != ALSMI_OK) return rc;
+    if (want_err && grid * 4 > pl->err_part_cap) grid = pl->err_part_cap / 4;
+    if (grid < 1) return ALSMI_OK;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    ALSMI_HIP_CHECK(hipGetLastError());
+    if (want_err) *n_err = grid * 4;
+    return ALSMI_OK;
+}
+
 template <typename T, int NV, int WPB>
 static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *indices,
                           const void *vals, const void *src, int64_t n_src, void *dst,
@@ -2705,6 +2916,7 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     bool dual = false;
     if constexpr (sizeof(T) == 4 && (NV == 8 || NV == 4))
         dual = !dump && is_f16x2(mode) && dual_enabled() && (NV == 8 || ablation() == 0);
+    if constexpr (sizeof(T) == 8 && (NV == 8 || NV == 4)) dual = !dump && dual_f64_enabled();
     int n_err = 0, used = 0;
     a.t_begin = 0;
     a.t_end = dual ? pl->t_dual[0] : pl->n_tasks;
@@ -2741,6 +2953,37 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
                     case 3: rc = launch_dual<NV, 3>(pl, a, err_out != nullptr, &used, st); break;
                     case 2: rc = launch_dual<NV, 2>(pl, a, err_out != nullptr, &used, st); break;
                     default: rc = launch_dual<NV, 1>(pl, a, err_out != nullptr, &used, st); break;
+                }
+                if (rc != ALSMI_OK) return rc;
+                n_err += used;
+            }
+        }
+    }
+    if constexpr (sizeof(T) == 8 && (NV == 8 || NV == 4)) {
+        if (dual) {
+            for (int k = 0; k < DUAL_CLASSES; ++k) {
+                a.err_part = pl->err_part + n_err;
+                a.t_begin = pl->t_dual[k];
+                a.t_end = pl->t_dual[k + 1];
+                used = 0;
+                const bool e = err_out != nullptr;
+                switch (DUAL_CLASSES - k) {
+#if DUAL_MAX_DEG_128 >= 96
+                    case 6:
+                        if constexpr (NV == 8) rc = launch_dual_d<NV, 6>(pl, a, e, &used, st);
+                        break;
+#endif
+#if DUAL_MAX_DEG_128 >= 80
+                    case 5:
+                        if constexpr (NV == 8) rc = launch_dual_d<NV, 5>(pl, a, e, &used, st);
+                        break;
+#endif
+                    case 4:
+                        if constexpr (NV == 8) rc = launch_dual_d<NV, 4>(pl, a, e, &used, st);
+                        break;
+                    case 3: rc = launch_dual_d<NV, 3>(pl, a, e, &used, st); break;
+                    case 2: rc = launch_dual_d<NV, 2>(pl, a, e, &used, st); break;
+                    default: rc = launch_dual_d<NV, 1>(pl, a, e, &used, st); break;
                 }
                 if (rc != ALSMI_OK) return rc;
                 n_err += used;
@@ -2855,7 +3098,7 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
         static const int forced = getenv("ALSMI_SOLVE_PRIO") ? atoi(getenv("ALSMI_SOLVE_PRIO")) : -1;
         pl->solve_prio = forced >= 0 ? forced : ((n > 0 && entries / n <= SOLVE_PRIO_MAX_MEAN ? 1 : 0) | 2);
     }
-    if (dtype == ALSMI_F32 && (kp == 128 || kp == 64)) {
+    if (kp == 128 || kp == 64) {
         // The n x n form is used for rows of at most 48 (padded rank 64) / 96 (128) entries AND
         // at most `rank` entries: with more entries than dimensions F F^T is rank deficient, its
         // condition number is that of the ridge alone, and fp32 loses rows the rank x rank
