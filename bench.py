@@ -72,7 +72,7 @@ def side_flops(indptr_host, rank, kp, dtype):
     """Arithmetic one half-sweep of a side issues, from its row lengths.
 
     Gram build: only the upper tiles of a row's kp x kp matrix are formed,
-    2 * entries * kp^2 * (NV+1)/(2 NV) with NV = kp/16; a short row (fp32, padded rank 64 or
+    2 * entries * kp^2 * (NV+1)/(2 NV) with NV = kp/16; a short row (padded rank 64 or
     128, at most min(rank, 48 or 96) entries) forms the n x n matrix of its neighbours
     instead, n = its entries padded to 16.  Solve: 2 (s^3/3 + 2 s^2) per row of an s x s system.
     Returns (gram_flops, solve_flops, matrix products issued per Gram product): in fp32 every
@@ -82,7 +82,7 @@ def side_flops(indptr_host, rank, kp, dtype):
     nv = kp // 16
     tri = (nv + 1) / (2.0 * nv)
     f32 = np.dtype(dtype) == np.float32
-    dual_max = min(rank, 48 if kp == 64 else 96) if (f32 and kp in (64, 128)) else 0
+    dual_max = min(rank, 48 if kp == 64 else 96) if kp in (64, 128) else 0
     short = (deg > 0) & (deg <= dual_max)
     n_pad = 16.0 * np.ceil(deg[short] / 16.0)
     nd = n_pad / 16.0
