@@ -16,6 +16,15 @@ import torch
 from . import device as dev
 
 
+def gather_mode():
+    """How the updated factor rows travel between ranks: 'p2p' (one batch of pairwise
+    transfers per gather, the default) or 'bcast' (one broadcast per owning rank)."""
+    mode = os.environ.get('ALSMI_GATHER', 'p2p')
+    if mode not in ('p2p', 'bcast'):
+        raise ValueError("ALSMI_GATHER must be 'p2p' or 'bcast'")
+    return mode
+
+
 def force_collectives():
     """ALSMI_FORCE_COLLECTIVES=1: a process group of ONE rank still goes through every
     collective of the multi-rank path (the broadcasts of the row gathers, the all-reduces),
@@ -311,16 +320,36 @@ class AlsEngine(object):
         return dev.factors_to_host(self.U, self.rank), dev.factors_to_host(self.V, self.rank)
 
     # ---- collectives --------------------------------------------------------
-    # The all-gather of updated factor rows is an all-gather-v done as one broadcast per
-    # owning rank, each straight from and into the rows of the factor table itself: the row
-    # ranges differ from rank to rank (they are balanced by stored entries), so nothing is
-    # padded, staged or copied afterwards, and the same calls serve RCCL on device tensors and
-    # gloo on host tensors.  (c10d's own all_gather of unequal tensors is the same group of
-    # broadcasts.)
+    # The all-gather of updated factor rows is an all-gather-v straight from and into the rows
+    # of the factor table itself: the row ranges differ from rank to rank (they are balanced by
+    # stored entries), so nothing is padded, staged or copied afterwards.  Every rank sends its
+    # rows to every other rank and receives theirs as ONE batch of point-to-point transfers
+    # (`batch_isend_irecv`: a single grouped launch on RCCL): xGMI links GPU pairs directly, so
+    # the 2 (N-1) transfers of a rank run side by side, each on the link of its pair, where a
+    # broadcast per owner would run one after the other.  ALSMI_GATHER=bcast selects those
+    # broadcasts instead (they are also what several ranks sharing one GPU under gloo use).
     def _bcast_rows(self, table, los, his, async_op):
         """Rank r sends rows [los[r], his[r]) of its `table` to the same rows of every other
         rank's table.  Returns the pending work handles (empty when blocking)."""
         import torch.distributed as dist
+        if not self._host_bounce and gather_mode() == 'p2p':
+            mine = table[int(los[self.me]):int(his[self.me])]
+            # (a group of one rank whose collectives are forced on exchanges with itself)
+            peers = [r for r in range(self.world) if r != self.me] or [self.me]
+            ops = []
+            for r in peers:
+                peer = dist.get_global_rank(self.group, r)
+                rows = table[int(los[r]):int(his[r])]
+                if mine.shape[0] > 0:
+                    ops.append(dist.P2POp(dist.isend, mine, peer, self.group))
+                if rows.shape[0] > 0:
+                    ops.append(dist.P2POp(dist.irecv, rows, peer, self.group))
+            works = dist.batch_isend_irecv(ops) if ops else []
+            if async_op:
+                return works
+            for w in works:
+                w.wait()
+            return []
         works = []
         for r in range(self.world):
             lo, hi = int(los[r]), int(his[r])

@@ -93,9 +93,13 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize('mode', ['p2p', 'bcast'])
 @pytest.mark.parametrize('world', [2, 3])
 @pytest.mark.parametrize('case', CASES, ids=['even', 'skewed'])
-def test_sharded_sweeps_match_single_process(tmp_path, world, case):
+def test_sharded_sweeps_match_single_process(tmp_path, world, case, mode, monkeypatch):
+    """Both forms of the row gather: the batch of pairwise transfers and the broadcast per
+    owning rank (the spawned ranks inherit ALSMI_GATHER)."""
+    monkeypatch.setenv('ALSMI_GATHER', mode)
     port = free_port()
     mp.spawn(worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
     seed, n, m, nnz, rank, extra = case

@@ -1,7 +1,8 @@
 """The multi-rank code path on RCCL with the one GPU at hand: a process group of ONE rank
-whose collectives are forced on (ALSMI_FORCE_COLLECTIVES=1), so that every broadcast of the
-slab gathers, the all-reduce of the squared error and the exchange of the slab bounds is a
-real RCCL call, asynchronous beside the kernels exactly as with eight ranks.  The factors must
+whose collectives are forced on (ALSMI_FORCE_COLLECTIVES=1), so that every transfer of the
+slab gathers (the batch of point-to-point transfers, here with the rank itself, and the
+broadcasts of ALSMI_GATHER=bcast), the all-reduce of the squared error and the exchange of the
+slab bounds is a real RCCL call, asynchronous beside the kernels exactly as with eight ranks.  The factors must
 equal those of the plain single-process path bit for bit (a row's arithmetic does not depend
 on how the rows are cut into slabs)."""
 import os
@@ -43,9 +44,11 @@ def rccl_group():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('mode', ['p2p', 'bcast'])
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
-def test_forced_gathers_on_rccl_match_the_plain_path(rccl_group, dtype):
+def test_forced_gathers_on_rccl_match_the_plain_path(rccl_group, dtype, mode, monkeypatch):
     import torch
+    monkeypatch.setenv('ALSMI_GATHER', mode)
     import torch.distributed as dist
     from alsmi import device as dev
     from alsmi import synth
