@@ -751,26 +751,34 @@ __device__ __forceinline__ void gram_accumulate(Gram<T, NV> &G, ErrAcc<T, NV, ER
 }
 
 // Largest |x| of a table as the bit pattern of a non-negative float (which orders like the
-// unsigned integer), combined with atomicMax into *out (zeroed by the caller).  NaN entries are
-// skipped here and propagate through the arithmetic instead.
+// unsigned integer), combined with atomicMax into *out, which is zero when the kernel starts:
+// the plan keeps two such words and every call zeroes the one the NEXT call accumulates into
+// (`next`), so no separate fill precedes the kernel.  NaN entries are skipped here and propagate
+// through the arithmetic instead.
 __global__ __launch_bounds__(256) void max_abs_kernel(const float *__restrict__ x, int64_t n4,
-                                                      unsigned *__restrict__ out) {
+                                                      unsigned *__restrict__ out,
+                                                      unsigned *__restrict__ next) {
     typedef float vec_t __attribute__((ext_vector_type(4)));
     __shared__ float part[4];
-    float m0 = 0.0f, m1 = 0.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next = 0u;
+    auto vmax = [](vec_t a) {
+        return fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
+    };
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + stride < n4; i += 2 * stride) {  // two independent loads in flight
+    for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent loads in flight
         const vec_t a = reinterpret_cast<const vec_t *>(x)[i];
         const vec_t b = reinterpret_cast<const vec_t *>(x)[i + stride];
-        m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
-        m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))));
+        const vec_t c = reinterpret_cast<const vec_t *>(x)[i + 2 * stride];
+        const vec_t d = reinterpret_cast<const vec_t *>(x)[i + 3 * stride];
+        m0 = fmaxf(m0, vmax(a));
+        m1 = fmaxf(m1, vmax(b));
+        m2 = fmaxf(m2, vmax(c));
+        m3 = fmaxf(m3, vmax(d));
     }
-    if (i < n4) {
-        const vec_t a = reinterpret_cast<const vec_t *>(x)[i];
-        m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
-    }
-    float m = fmaxf(m0, m1);
+    for (; i < n4; i += stride) m0 = fmaxf(m0, vmax(reinterpret_cast<const vec_t *>(x)[i]));
+    float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
@@ -2681,7 +2689,10 @@ struct alsmi_plan {
     size_t slab_bytes;
     double *err_part;  // one squared-error partial per wave of the solve grid
     int err_part_cap;
-    unsigned *max_bits;  // bit pattern of the largest |source factor| of the running call
+    unsigned *max_bits;  // two words: bit pattern of the largest |source factor| of the running
+                         // call in word max_slot ^ 1 (after the call's first kernel), the other
+                         // one zeroed for the next call
+    int max_slot;
 };
 
 namespace alsmi {
@@ -2836,6 +2847,7 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
                           double *err_out, hipStream_t st) {
     const bool dump = A_out != nullptr;
     int mode = GRAM_NATIVE;
+    unsigned *max_word = pl->max_bits;
     if constexpr (sizeof(T) == 4 && NV <= 8) {
         mode = GRAM_F16X2;  // the dump included: it accumulates as the half-sweep does
         if constexpr (NV == 4) {
@@ -2855,14 +2867,17 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
                     ALSMI_REQUIRE(n_src * (int64_t)(NV * 16) * 4 <= (int64_t)UINT32_MAX,
                                   "alsmi_normal_equations: source table above 4 GiB");
             }
-            // scale of the fp16 split: the largest magnitude of the source table
-            ALSMI_HIP_CHECK(hipMemsetAsync(pl->max_bits, 0, sizeof(unsigned), st));
+            // scale of the fp16 split: the largest magnitude of the source table, into the word
+            // the previous call left zeroed
+            max_word = pl->max_bits + pl->max_slot;
             const int64_t n4 = n_src * (int64_t)(NV * 16) / 4;
             int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2 * (int64_t)pl->cu_count);
             if (blocks < 1) blocks = 1;
             hipLaunchKernelGGL(max_abs_kernel, dim3(blocks), dim3(256), 0, st,
-                               static_cast<const float *>(src), n4, pl->max_bits);
+                               static_cast<const float *>(src), n4, max_word,
+                               pl->max_bits + (pl->max_slot ^ 1));
             ALSMI_HIP_CHECK(hipGetLastError());
+            pl->max_slot ^= 1;
         }
     }
     if (pl->n_chunks > 0) {
@@ -2882,7 +2897,7 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
         }
         hipLaunchKernelGGL(chunks, dim3(grid), dim3(256), 0, st, pl->ch_beg, pl->ch_end,
                            pl->n_chunks, indices, static_cast<const T *>(vals),
-                           static_cast<const T *>(src), pl->max_bits, static_cast<T *>(pl->slabs));
+                           static_cast<const T *>(src), max_word, static_cast<T *>(pl->slabs));
         ALSMI_HIP_CHECK(hipGetLastError());
         const int slab_elems = Gram<T, NV>::SLAB_SLOTS * WAVE;
         const int per_row = (slab_elems + 255) / 256;
@@ -2900,7 +2915,7 @@ static int run_half_sweep(alsmi_plan *pl, const int64_t *indptr, const int32_t *
     a.vals = static_cast<const T *>(vals);
     a.src = static_cast<const T *>(src);
     a.slabs = static_cast<const T *>(pl->slabs);
-    a.max_bits = pl->max_bits;
+    a.max_bits = max_word;
     a.dst = static_cast<T *>(dst);
     a.rank = pl->rank;
     a.alpha = (T)alpha;
@@ -3128,7 +3143,8 @@ int alsmi_plan_create(alsmi_plan **out, const int64_t *indptr_host, int64_t n_ro
     if (e == hipSuccess) e = upload((void **)&pl->ch_beg, ch_beg.data(), ch_beg.size() * 8);
     if (e == hipSuccess) e = upload((void **)&pl->ch_end, ch_end.data(), ch_end.size() * 8);
     if (e == hipSuccess) e = upload(&pl->slabs, nullptr, pl->slab_bytes);
-    if (e == hipSuccess) e = upload((void **)&pl->max_bits, nullptr, sizeof(unsigned));
+    if (e == hipSuccess) e = upload((void **)&pl->max_bits, nullptr, 2 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(pl->max_bits, 0, 2 * sizeof(unsigned));
     pl->err_part_cap = pl->cu_count * 64;
     if (e == hipSuccess)
         e = upload((void **)&pl->err_part, nullptr,
