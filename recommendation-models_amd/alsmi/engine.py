@@ -9,6 +9,7 @@ xGMI when the backend is "nccl"), the training error with an all-reduce of the
 squared-error sum.
 """
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -164,6 +165,7 @@ class AlsEngine(object):
                 total_nnz = int(t.cpu()[0])
         self.nnz = int(total_nnz)
         self._host_bounce = False
+        self._p2p_refused = False
         if self.collective:
             import torch.distributed as dist
             self._host_bounce = self.U.is_cuda and dist.get_backend(group) == 'gloo'
@@ -332,7 +334,7 @@ class AlsEngine(object):
         """Rank r sends rows [los[r], his[r]) of its `table` to the same rows of every other
         rank's table.  Returns the pending work handles (empty when blocking)."""
         import torch.distributed as dist
-        if not self._host_bounce and gather_mode() == 'p2p':
+        if not self._host_bounce and gather_mode() == 'p2p' and not self._p2p_refused:
             mine = table[int(los[self.me]):int(his[self.me])]
             # (a group of one rank whose collectives are forced on exchanges with itself)
             peers = [r for r in range(self.world) if r != self.me] or [self.me]
@@ -344,7 +346,15 @@ class AlsEngine(object):
                     ops.append(dist.P2POp(dist.isend, mine, peer, self.group))
                 if rows.shape[0] > 0:
                     ops.append(dist.P2POp(dist.irecv, rows, peer, self.group))
-            works = dist.batch_isend_irecv(ops) if ops else []
+            try:
+                works = dist.batch_isend_irecv(ops) if ops else []
+            except (RuntimeError, ValueError, NotImplementedError) as err:
+                # a backend that refuses batched point-to-point transfers outright (every rank
+                # gets the same refusal before anything is sent): the broadcasts below serve
+                warnings.warn('alsmi: batched point-to-point gather refused (%s); using one '
+                              'broadcast per owning rank' % err)
+                self._p2p_refused = True
+                return self._bcast_rows(table, los, his, async_op)
             if async_op:
                 return works
             for w in works:
