@@ -201,6 +201,51 @@ def test_rows_of_65_to_96_entries_at_padded_rank_128(gpu, rank, dtype):
     plan.close()
 
 
+@pytest.mark.parametrize('rank', [128, 96, 90, 64, 50, 33])
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_row_lengths_at_the_kernel_class_boundaries(gpu, rank, dtype):
+    """Rows of exactly 1, 15, 16, 17, ... 95, 96, 97, 127, 128, 129 entries: every boundary
+    between the kernels a plan deals its rows to (the neighbour-by-neighbour form in classes of
+    16 entries up to min(rank, 48 or 96), the rank x rank form above), each row against the
+    oracle (src/als.py:244-247), plain and with the error of the replaced vectors."""
+    device, torch = gpu
+    from alsmi import device as dev
+    from oracle import als_oracle as ao
+    lengths = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 79, 80, 81, 95, 96, 97, 111,
+               112, 113, 127, 128, 129, 200]
+    lengths = lengths + [rank - 1, rank, rank + 1]
+    m = 400
+    rng = np.random.default_rng(900 + rank)
+    n = len(lengths)
+    indptr = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(m, k, replace=False)) for k in lengths]) \
+        .astype(np.int32)
+    vals = rng.integers(1, 11, indices.size).astype(np.float64) / 2
+    V0 = rng.standard_normal((rank, m)) * 0.5 + 0.3
+    U0 = rng.standard_normal((rank, n)) * 0.5 + 0.3
+    alpha = 0.02
+    side = dev.SparseSide(indptr, indices, vals, n, m, dtype, device)
+    plan = dev.SweepPlan(side, rank)
+    V = dev.factors_to_device(V0, dtype, device)
+    Ucur = dev.factors_to_device(U0, dtype, device)
+    Vq = dev.factors_to_host(V, rank)
+    kp = dev.padded_rank(rank)
+    out = torch.full((n, kp), 7.0, dtype=V.dtype, device=device)
+    plan.half_sweep(V, out, alpha)
+    want = ao.half_sweep(indptr, indices, vals, Vq, rank, alpha)
+    got = dev.factors_to_host(out, rank)
+    err = np.linalg.norm(got - want, axis=0) / np.linalg.norm(want, axis=0)
+    tol = 1e-4 if dtype == 'float32' else 1e-10
+    assert err.max() < tol, (lengths[int(np.argmax(err))], err.max())
+    assert not out[:, rank:].any()
+    out2 = torch.full((n, kp), 7.0, dtype=V.dtype, device=device)
+    sse = plan.half_sweep_err(V, Ucur, out2, alpha)
+    assert col_rel_err(dev.factors_to_host(out2, rank), got) < (1e-5 if dtype == 'float32' else 1e-12)
+    want_sse = ao.train_sse(indptr, indices, vals, dev.factors_to_host(Ucur, rank), Vq)
+    assert abs(float(sse.cpu()[0]) - want_sse) <= (2e-5 if dtype == 'float32' else 1e-12) * want_sse
+    plan.close()
+
+
 @pytest.mark.parametrize('dtype,rank', [('float32', 64), ('float32', 20), ('float32', 128),
                                         ('float64', 64)])
 def test_half_sweep_is_reproducible(gpu, dtype, rank):
