@@ -160,7 +160,14 @@ int alsmi_sddmm_noalloc(int dtype, int rank, int64_t n_pairs, const int32_t *use
  * with the same result.  ALSMI_F32 scores are formed on the fp16 matrix cores from a scaled
  * two-way fp16 split of both tables (scales from the largest |factor| of the selected users
  * and of the items): fp32 accuracy, the same bits for the same pair of vectors within a
- * call.  Deterministic.  Scores are ranked by their bit
+ * call.  ALSMI_F64 in that form: the candidates come from the fp32 pass on the tables rounded
+ * to fp32, with every user's threshold lowered by twice a bound of the fp32 scores' error
+ * (2^-13 |u| max_i |v_i|), and those within that distance of the user's k-th best fp32 score
+ * are scored again in fp64 from the fp64 tables and ranked by those scores — the lists are
+ * those of fp64 scores of all items; the last bits of a score may differ from the dense block's
+ * (another summation order), i.e. between calls that batch the users differently.
+ * ALSMI_TOPK_F64_PREFILTER=0: fp64 scores of all items on the fp64 matrix pipe instead.
+ * Deterministic.  Scores are ranked by their bit
  * pattern in the total order of IEEE 754: -0.0 ranks below +0.0 (they do not tie), and a NaN
  * score with a clear sign bit ranks above +infinity, i.e. first (one with the sign bit set
  * below -infinity, last); finite factor tables never produce one. */

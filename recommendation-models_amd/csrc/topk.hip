@@ -594,6 +594,222 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(const int *__restr
     }
 }
 
+
+// ---- fp64 lists through an fp32 filter ---------------------------------------------------------
+// Scoring all users x items in fp64 costs sixteen times the matrix-pipe time of the fp32 pass
+// on the 16-bit cores, and almost all of those scores are thrown away.  With d_u a bound on
+// |s32(u,i) - s64(u,i)| for every item (s32: the fp32 pass on the factors rounded to fp32),
+// the k-th largest s32 of a user, t32, is at most d_u above the k-th largest s64, so every item
+// of the user's fp64 top k has s32 >= t32 - 2 d_u.  The fp32 filtered form therefore runs with
+// its thresholds lowered by 2 d_u, and only the few candidates at or above t32 - 2 d_u are
+// scored again in fp64 (from the fp64 tables) and ranked by those scores: the lists are exactly
+// those of fp64 scores of all items.  d_u = 2^-13 |u| max_i |v_i|: rounding the factors to fp32
+// (2^-23 per product), the two-way fp16 split (2^-20) and 3 x 128 fp32 additions (2^-15.4, were
+// every one off by a whole ulp) stay below 2^-15 sum_d |u_d v_d| <= 2^-15 |u| |v_i|.
+// Non-finite or overflowing factors make every item a candidate; the lists overflow and the
+// call falls back to the dense fp64 form like any other overflow.
+constexpr float TOPK_F64_MARGIN = 1.0f / 8192.0f;  // 2^-13
+
+// Rows of an fp64 table (rows[] when not null, else rows 0 .. n_rows-1) to fp32, one wave per row;
+// the row's Euclidean norm, rounded up (norm_out and/or its maximum in *maxnorm_bits) and the
+// largest |fp32 value| (*maxabs_bits); the two maxima as bit patterns of non-negative floats,
+// which order like unsigned integers, zeroed by the caller.
+__global__ __launch_bounds__(256) void topk_to_f32_kernel(int64_t n_rows,
+                                                          const int32_t *__restrict__ rows,
+                                                          const double *__restrict__ table, int kp,
+                                                          float *__restrict__ dst,
+                                                          float *__restrict__ norm_out,
+                                                          unsigned *__restrict__ maxnorm_bits,
+                                                          unsigned *__restrict__ maxabs_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;  // (a whole wave)
+    const int64_t src = rows ? (int64_t)rows[r] : r;
+    double n2 = 0.0;
+    float mx = 0.0f;
+    for (int d = lane; d < kp; d += 64) {
+        const double x = table[src * kp + d];
+        const float f = (float)x;
+        dst[r * kp + d] = f;
+        n2 += x * x;
+        mx = fmaxf(mx, fabsf(f));
+    }
+    n2 = wave_sum(n2);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) {
+        // (NaN propagates: a NaN norm makes the user's margin NaN and every item a candidate)
+        const float nf = (float)sqrt(n2) * 1.0001f;
+        if (norm_out) norm_out[r] = nf;
+        // (most rows are below the running maximum: look before the atomic)
+        if (maxnorm_bits) {
+            const unsigned b = nf == nf ? __builtin_bit_cast(unsigned, nf) : 0x7f800000u;
+            if (b > *reinterpret_cast<volatile unsigned *>(maxnorm_bits)) atomicMax(maxnorm_bits, b);
+        }
+        const unsigned mb = __builtin_bit_cast(unsigned, mx);
+        if (mb > *reinterpret_cast<volatile unsigned *>(maxabs_bits)) atomicMax(maxabs_bits, mb);
+    }
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(int n, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+// margin2[u] = 2 d_u and the lowered threshold of the filter pass: the k-th best sampled fp32
+// score of user u (sample_best[u * k + k - 1]) minus it.
+__global__ __launch_bounds__(256) void topk_f64_margin_kernel(int n_sel, int k,
+                                                              const float *__restrict__ sample_best,
+                                                              const float *__restrict__ unorm,
+                                                              const unsigned *__restrict__ vnorm_bits,
+                                                              float *__restrict__ margin2,
+                                                              float *__restrict__ thr_low) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_sel) return;
+    const float vmax = __builtin_bit_cast(float, vnorm_bits[0]);
+    const float m2 = 2.0f * TOPK_F64_MARGIN * unorm[u] * vmax;
+    margin2[u] = m2;
+    thr_low[u] = sample_best[(int64_t)u * k + k - 1] - m2;
+}
+
+// One workgroup per user: the user's fp32 candidates sorted by (fp32 score descending, item
+// ascending); those at or above (k-th fp32 score - margin2) scored again in fp64 — sixteen lanes
+// per candidate, each a fixed share of the dimensions, summed in a fixed order, so a score depends
+// on its two vectors only —, sorted by (fp64 score descending, item ascending), the first k
+// written out.  Overflowing lists raise *overflow as in topk_candidates_kernel.
+template <int NV>
+__global__ __launch_bounds__(256) void topk_rescore_kernel(
+    const int *__restrict__ count, const int32_t *__restrict__ cand_item,
+    const float *__restrict__ cand_score, int64_t n_wchunks, int k, const int32_t *__restrict__ sel,
+    const double *__restrict__ U, const double *__restrict__ V, const float *__restrict__ margin2,
+    int32_t *__restrict__ out_idx, double *__restrict__ out_score, int *__restrict__ overflow) {
+    constexpr int KP = NV * 16;
+    __shared__ unsigned ckey[TOPK_CAND];
+    __shared__ int32_t cidx[TOPK_CAND];
+    __shared__ unsigned long long dkey[TOPK_CAND];
+    __shared__ int n_sh, bad_sh, r_sh;
+    const int tid = threadIdx.x;
+    const int64_t u = blockIdx.x;
+    if (tid == 0) {
+        n_sh = 0;
+        bad_sh = 0;
+        r_sh = 0;
+    }
+    __syncthreads();
+    for (int64_t w = tid; w < n_wchunks; w += 256) {
+        const int c = count[u * n_wchunks + w];
+        if (c == 0) continue;
+        if (c > TOPK_CHUNK_CAND) {
+            bad_sh = 1;
+            continue;
+        }
+        const int at = atomicAdd(&n_sh, c);
+        if (at + c > TOPK_CAND) {
+            bad_sh = 1;
+            continue;
+        }
+        const int64_t from = (u * n_wchunks + w) * TOPK_CHUNK_CAND;
+        for (int i = 0; i < c; ++i) {
+            ckey[at + i] = key_of(cand_score[from + i]);
+            cidx[at + i] = cand_item[from + i];
+        }
+    }
+    __syncthreads();
+    if (bad_sh || n_sh < k) {  // (fewer than k candidates cannot happen with finite scores)
+        if (tid == 0) atomicOr(overflow, 1);
+        return;
+    }
+    const int n = n_sh;
+    auto sort32 = [&](int np2) {
+        for (int size = 2; size <= np2; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < np2 / 2; i += 256) {
+                    const int lo = 2 * i - (i & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const bool lo_better = ckey[lo] > ckey[hi] ||
+                                           (ckey[lo] == ckey[hi] && cidx[lo] < cidx[hi]);
+                    if (lo_better != up) {
+                        const unsigned tk = ckey[lo];
+                        ckey[lo] = ckey[hi];
+                        ckey[hi] = tk;
+                        const int32_t ti = cidx[lo];
+                        cidx[lo] = cidx[hi];
+                        cidx[hi] = ti;
+                    }
+                }
+                __syncthreads();
+            }
+    };
+    int np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + tid; i < np2; i += 256) {
+        ckey[i] = 0u;
+        cidx[i] = INT32_MAX;
+    }
+    __syncthreads();
+    sort32(np2);
+    // the candidates to score again: the leading ones down to the cut ("not below": NaN stays in)
+    const float cut = score_of(ckey[k - 1]) - margin2[u];
+    for (int i = tid; i < n; i += 256) {
+        const bool in = !(score_of(ckey[i]) < cut);
+        const bool next_in = i + 1 < n && !(score_of(ckey[i + 1]) < cut);
+        if (in && !next_in) atomicMax(&r_sh, i + 1);
+    }
+    __syncthreads();
+    const int R = r_sh < k ? k : r_sh;
+    // fp64 scores: lane ql of a group of 16 takes dimensions ql, ql + 16, ...
+    const int grp = tid >> 4, ql = tid & 15;
+    const double *urow = U + (int64_t)sel[u] * KP;
+    double ur[KP / 16];
+#pragma unroll
+    for (int j = 0; j < KP / 16; ++j) ur[j] = urow[ql + 16 * j];
+    for (int c0 = 0; c0 < R; c0 += 16) {
+        const int c = c0 + grp;
+        const int32_t item = cidx[c < R ? c : R - 1];
+        const double *vrow = V + (int64_t)item * KP;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < KP / 16; ++j) acc = fma(ur[j], vrow[ql + 16 * j], acc);
+        acc += __shfl_xor(acc, 8);
+        acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 1);
+        if (ql == 0 && c < R) dkey[c] = key_of(acc);
+    }
+    __syncthreads();
+    int rp2 = 2;
+    while (rp2 < R) rp2 <<= 1;
+    for (int i = R + tid; i < rp2; i += 256) {
+        dkey[i] = 0ull;
+        cidx[i] = INT32_MAX;
+    }
+    __syncthreads();
+    for (int size = 2; size <= rp2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < rp2 / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const bool lo_better = dkey[lo] > dkey[hi] ||
+                                       (dkey[lo] == dkey[hi] && cidx[lo] < cidx[hi]);
+                if (lo_better != up) {
+                    const unsigned long long tk = dkey[lo];
+                    dkey[lo] = dkey[hi];
+                    dkey[hi] = tk;
+                    const int32_t ti = cidx[lo];
+                    cidx[lo] = cidx[hi];
+                    cidx[hi] = ti;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k; i += 256) {
+        out_idx[u * k + i] = cidx[i];
+        out_score[u * k + i] = score_of(dkey[i]);
+    }
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Users per wave of the score kernel of (T, NV).
@@ -673,7 +889,89 @@ static int run_topk(int n_sel, const int32_t *sel, const void *U, const void *V,
     const size_t off_score = off_item + align_up((size_t)n_sel * n_wchunks * TOPK_CHUNK_CAND *
                                                  sizeof(int32_t), 256);
     const size_t need = off_score + (size_t)n_sel * n_wchunks * TOPK_CHUNK_CAND * sizeof(T);
-    if (s_tiles > 0 && need <= block_bytes) {
+    bool prefiltered = false;
+    if constexpr (sizeof(T) == 8) {
+        // fp64 through the fp32 filter (see topk_rescore_kernel); everything it needs lies in
+        // the dense block's memory, which the fallback only touches if the flag is raised
+        static const bool pre_on =
+            !(getenv("ALSMI_TOPK_F64_PREFILTER") && atoi(getenv("ALSMI_TOPK_F64_PREFILTER")) == 0);
+        constexpr int kp = NV * 16;
+        constexpr int UPW32 = score_users_per_wave<float, NV>();
+        const int64_t ub32 = (n_sel + UPW32 - 1) / UPW32;
+        const int itw32 = ub32 >= 64 ? 32 : 4;
+        const int64_t chunks32 = (n_tiles + 4 * itw32 - 1) / (4 * itw32);
+        const int64_t nw32 = (n_tiles + itw32 - 1) / itw32;
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            const size_t at = off;
+            off += align_up(bytes, 256);
+            return at;
+        };
+        const size_t o_u32 = take((size_t)n_sel * kp * 4), o_v32 = take((size_t)n_items * kp * 4);
+        const size_t o_ident = take((size_t)n_sel * 4), o_unorm = take((size_t)n_sel * 4);
+        const size_t o_margin = take((size_t)n_sel * 4), o_thr = take((size_t)n_sel * 4);
+        const size_t o_bidx = take((size_t)n_sel * k * 4), o_bs = take((size_t)n_sel * k * 4);
+        const size_t o_sample = take((size_t)n_sel * s_tiles * 16 * 4);
+        const size_t o_count = take((size_t)n_sel * nw32 * sizeof(int));
+        const size_t o_citem = take((size_t)n_sel * nw32 * TOPK_CHUNK_CAND * 4);
+        const size_t o_cscore = take((size_t)n_sel * nw32 * TOPK_CHUNK_CAND * 4);
+        if (pre_on && s_tiles > 0 && off <= block_bytes && chunks32 <= 65535) {
+            char *base = static_cast<char *>(workspace);
+            int *flag_w = reinterpret_cast<int *>(tail);
+            unsigned *vnorm_bits = reinterpret_cast<unsigned *>(tail + 32);
+            float *U32 = reinterpret_cast<float *>(base + o_u32);
+            float *V32 = reinterpret_cast<float *>(base + o_v32);
+            int32_t *ident = reinterpret_cast<int32_t *>(base + o_ident);
+            float *unorm = reinterpret_cast<float *>(base + o_unorm);
+            float *margin2 = reinterpret_cast<float *>(base + o_margin);
+            float *thr_low = reinterpret_cast<float *>(base + o_thr);
+            int32_t *best_idx = reinterpret_cast<int32_t *>(base + o_bidx);
+            float *best_s = reinterpret_cast<float *>(base + o_bs);
+            ALSMI_HIP_CHECK(hipMemsetAsync(tail, 0, 64, st));  // flag, the two scales, the norm
+            hipLaunchKernelGGL(topk_to_f32_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0,
+                               st, (int64_t)n_sel, sel, reinterpret_cast<const double *>(Ut), kp,
+                               U32, unorm, (unsigned *)nullptr, max_bits);
+            hipLaunchKernelGGL(topk_to_f32_kernel, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0,
+                               st, n_items, (const int32_t *)nullptr,
+                               reinterpret_cast<const double *>(Vt), kp, V32, (float *)nullptr,
+                               vnorm_bits, max_bits + 1);
+            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, st,
+                               n_sel, ident);
+            ALSMI_HIP_CHECK(hipGetLastError());
+            ScoreOut<float> o = {};
+            o.scores = reinterpret_cast<float *>(base + o_sample);
+            o.row_len = s_tiles * 16;
+            o.tile_stride = (n_items / 16) / s_tiles;
+            const int64_t s_chunks = (s_tiles + 4 * itw32 - 1) / (4 * itw32);
+            launch_scores<float, NV, 1>(dim3((unsigned)ub32, (unsigned)s_chunks), st, n_sel, ident,
+                                        U32, V32, n_items, o, itw32, max_bits);
+            ALSMI_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL((topk_select_kernel<float>), dim3(n_sel), dim3(256), 0, st, o.scores,
+                               (int64_t)(s_tiles * 16), k, best_idx, best_s, (const int *)nullptr);
+            hipLaunchKernelGGL(topk_f64_margin_kernel, dim3((unsigned)((n_sel + 255) / 256)),
+                               dim3(256), 0, st, n_sel, k, best_s, unorm, vnorm_bits, margin2,
+                               thr_low);
+            ALSMI_HIP_CHECK(hipGetLastError());
+            o.thresh = thr_low;
+            o.thresh_stride = 1;
+            o.count = reinterpret_cast<int *>(base + o_count);
+            o.cand_item = reinterpret_cast<int32_t *>(base + o_citem);
+            o.cand_score = reinterpret_cast<float *>(base + o_cscore);
+            o.n_wchunks = nw32;
+            launch_scores<float, NV, 2>(dim3((unsigned)ub32, (unsigned)chunks32), st, n_sel, ident,
+                                        U32, V32, n_items, o, itw32, max_bits);
+            ALSMI_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL((topk_rescore_kernel<NV>), dim3(n_sel), dim3(256), 0, st, o.count,
+                               o.cand_item, o.cand_score, nw32, k, sel,
+                               reinterpret_cast<const double *>(Ut),
+                               reinterpret_cast<const double *>(Vt), margin2, out_idx,
+                               reinterpret_cast<double *>(out_s), flag_w);
+            ALSMI_HIP_CHECK(hipGetLastError());
+            flag = flag_w;
+            prefiltered = true;
+        }
+    }
+    if (!prefiltered && s_tiles > 0 && need <= block_bytes) {
         char *base = static_cast<char *>(workspace);
         int *flag_w = reinterpret_cast<int *>(tail);
         int *count = reinterpret_cast<int *>(base + off_count);

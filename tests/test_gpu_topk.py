@@ -201,5 +201,53 @@ def test_topk_filtered_form_matches_dense_ranking(dtype, rank, m, k):
     # the same users, batched differently (another workspace limit), give the same lists
     again, sc_again = dev.topk_items(rank, torch.from_numpy(users).to(device), Ud, Vd, k,
                                      max_workspace_bytes=m * 8 * 33)
-    np.testing.assert_array_equal(again.cpu().numpy(), items)
-    np.testing.assert_array_equal(sc_again.to(torch.float64).cpu().numpy(), scores)
+    sc_again = sc_again.to(torch.float64).cpu().numpy()
+    if dtype == 'float32':
+        np.testing.assert_array_equal(again.cpu().numpy(), items)
+        np.testing.assert_array_equal(sc_again, scores)
+    else:
+        # fp64 lists come from an fp32 filter whose candidates are scored again in fp64, or —
+        # when a user's candidate slots overflow, per call — from the dense fp64 block: the
+        # two sum a score in different orders, so the last bits may differ between batchings
+        np.testing.assert_allclose(sc_again, scores, rtol=1e-14, atol=1e-14)
+        differ = again.cpu().numpy() != items
+        assert np.abs(sc_again[differ] - scores[differ]).max(initial=0) < 1e-12
+
+
+@pytest.mark.parametrize('rank,k', [(64, 50), (128, 10), (20, 200)])
+def test_topk_fp64_ranks_scores_that_fp32_cannot_tell_apart(rank, k):
+    """fp64 lists from 8192 items on come from an fp32 filter plus fp64 scores of the candidates
+    (src/als.py:347-364 ranks fp64 scores).  300 items spread over the table whose vectors differ
+    by a few 1e-9 are every user's best: fp32 scores cannot order them, the filter must keep them
+    all and the fp64 scores of the candidates must give exactly numpy's fp64 ranking."""
+    import torch
+    from alsmi import device as dev
+    device = dev.require_gpu()
+    rng = np.random.default_rng(31 + rank)
+    n, m = 40, 30000
+    U = rng.standard_normal((rank, n))
+    V = rng.standard_normal((rank, m)) * 0.2
+    group = np.arange(300) * 97 + 5
+    centre = U.mean(axis=1) * 3 + rng.standard_normal(rank) * 0.1
+    step = rng.standard_normal((rank, 300)) * 3e-9
+    V[:, group] = centre[:, None] + step
+    U = U * 0.2 + U.mean(axis=1, keepdims=True) * 2        # every user likes the group best
+    Ud = dev.factors_to_device(U, 'float64', device)
+    Vd = dev.factors_to_device(V, 'float64', device)
+    users = np.arange(n, dtype=np.int32)
+    items, scores = dev.topk_items(rank, torch.from_numpy(users).to(device), Ud, Vd, k)
+    items, scores = items.cpu().numpy().astype(np.int64), scores.cpu().numpy()
+    Uq, Vq = dev.factors_to_host(Ud, rank), dev.factors_to_host(Vd, rank)
+    dense = Uq.T.dot(Vq)
+    order = np.lexsort((np.broadcast_to(np.arange(m), dense.shape), -dense), axis=1)[:, :k]
+    assert np.isin(order, group).all()                     # the test is about the group
+    want_scores = np.take_along_axis(dense, order, axis=1)
+    np.testing.assert_allclose(scores, want_scores, rtol=1e-13)
+    differ = items != order
+    # neighbours in the ranking are about 1e-9 apart: the lists agree except where two fp64
+    # scores agree to rounding
+    assert np.abs(scores[differ] - want_scores[differ]).max(initial=0) < 1e-13
+    assert differ.mean() < 0.01
+    gaps = -np.diff(want_scores, axis=1)
+    assert np.median(gaps) < 1e-7 and (np.diff(scores, axis=1) <= 0).all()
+
