@@ -610,44 +610,77 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(const int *__restr
 // call falls back to the dense fp64 form like any other overflow.
 constexpr float TOPK_F64_MARGIN = 1.0f / 8192.0f;  // 2^-13
 
-// Rows of an fp64 table (rows[] when not null, else rows 0 .. n_rows-1) to fp32, one wave per row;
-// the row's Euclidean norm, rounded up (norm_out and/or its maximum in *maxnorm_bits) and the
-// largest |fp32 value| (*maxabs_bits); the two maxima as bit patterns of non-negative floats,
-// which order like unsigned integers, zeroed by the caller.
+// Rows of an fp64 table (rows[] when not null, else rows 0 .. n_rows-1) to fp32, sixteen lanes per
+// row (EL = kp / 16 consecutive dimensions each), the waves striding over the rows; the row's
+// Euclidean norm, rounded up (norm_out and/or its maximum in *maxnorm_bits) and the largest
+// |fp32 value| (*maxabs_bits); the two maxima as bit patterns of non-negative floats, which
+// order like unsigned integers, zeroed by the caller: one atomic per block.
+template <int EL>
 __global__ __launch_bounds__(256) void topk_to_f32_kernel(int64_t n_rows,
                                                           const int32_t *__restrict__ rows,
-                                                          const double *__restrict__ table, int kp,
+                                                          const double *__restrict__ table,
                                                           float *__restrict__ dst,
                                                           float *__restrict__ norm_out,
                                                           unsigned *__restrict__ maxnorm_bits,
                                                           unsigned *__restrict__ maxabs_bits) {
+    constexpr int KP = 16 * EL;
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rows) return;  // (a whole wave)
-    const int64_t src = rows ? (int64_t)rows[r] : r;
-    double n2 = 0.0;
-    float mx = 0.0f;
-    for (int d = lane; d < kp; d += 64) {
-        const double x = table[src * kp + d];
-        const float f = (float)x;
-        dst[r * kp + d] = f;
-        n2 += x * x;
-        mx = fmaxf(mx, fabsf(f));
-    }
-    n2 = wave_sum(n2);
+    const int sub = lane >> 4, ql = lane & 15;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    float mx = 0.0f, mn = 0.0f;
+    bool nan_norm = false;
+    for (int64_t r0 = 4 * wave; r0 < n_rows; r0 += 4 * n_waves) {
+        const int64_t r = r0 + sub;
+        double n2 = 0.0;
+        if (r < n_rows) {
+            const int64_t src = rows ? (int64_t)rows[r] : r;
+            double x[EL];
+            load_vec<double, EL>(x, table + src * KP + ql * EL);
+            float f[EL];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if (lane == 0) {
+            for (int e = 0; e < EL; ++e) {
+                f[e] = (float)x[e];
+                n2 += x[e] * x[e];
+                mx = fmaxf(mx, fabsf(f[e]));
+            }
+            typedef float vec_t __attribute__((ext_vector_type(EL)));
+            vec_t v;
+#pragma unroll
+            for (int e = 0; e < EL; ++e) {
+                if constexpr (EL == 1) v = f[e];
+                else v[e] = f[e];
+            }
+            *reinterpret_cast<vec_t *>(dst + r * KP + ql * EL) = v;
+        }
+        n2 += __shfl_xor(n2, 8);
+        n2 += __shfl_xor(n2, 4);
+        n2 += __shfl_xor(n2, 2);
+        n2 += __shfl_xor(n2, 1);
         // (NaN propagates: a NaN norm makes the user's margin NaN and every item a candidate)
         const float nf = (float)sqrt(n2) * 1.0001f;
-        if (norm_out) norm_out[r] = nf;
-        // (most rows are below the running maximum: look before the atomic)
-        if (maxnorm_bits) {
-            const unsigned b = nf == nf ? __builtin_bit_cast(unsigned, nf) : 0x7f800000u;
-            if (b > *reinterpret_cast<volatile unsigned *>(maxnorm_bits)) atomicMax(maxnorm_bits, b);
-        }
-        const unsigned mb = __builtin_bit_cast(unsigned, mx);
-        if (mb > *reinterpret_cast<volatile unsigned *>(maxabs_bits)) atomicMax(maxabs_bits, mb);
+        if (norm_out && r < n_rows && ql == 0) norm_out[r] = nf;
+        nan_norm = nan_norm || nf != nf;
+        mn = fmaxf(mn, nf);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+        mn = fmaxf(mn, __shfl_xor(mn, off));
+    }
+    // one atomic per block and word (they all go to two addresses and are served one by one)
+    __shared__ unsigned part[2][4];
+    const bool any_nan = __any(nan_norm);
+    if (lane == 0) {
+        part[0][threadIdx.x >> 6] = any_nan ? 0x7fc00000u : __builtin_bit_cast(unsigned, mn);
+        part[1][threadIdx.x >> 6] = __builtin_bit_cast(unsigned, mx);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned *p4 = part[threadIdx.x];
+        const unsigned a = p4[0] > p4[1] ? p4[0] : p4[1], b = p4[2] > p4[3] ? p4[2] : p4[3];
+        unsigned *word = threadIdx.x == 0 ? maxnorm_bits : maxabs_bits;
+        if (word) atomicMax(word, a > b ? a : b);
     }
 }
 
@@ -928,12 +961,16 @@ static int run_topk(int n_sel, const int32_t *sel, const void *U, const void *V,
             int32_t *best_idx = reinterpret_cast<int32_t *>(base + o_bidx);
             float *best_s = reinterpret_cast<float *>(base + o_bs);
             ALSMI_HIP_CHECK(hipMemsetAsync(tail, 0, 64, st));  // flag, the two scales, the norm
-            hipLaunchKernelGGL(topk_to_f32_kernel, dim3((unsigned)((n_sel + 3) / 4)), dim3(256), 0,
-                               st, (int64_t)n_sel, sel, reinterpret_cast<const double *>(Ut), kp,
-                               U32, unorm, (unsigned *)nullptr, max_bits);
-            hipLaunchKernelGGL(topk_to_f32_kernel, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0,
+            auto conv_blocks = [](int64_t rows) {  // four waves of four rows per block and turn
+                const int64_t b = (rows + 15) / 16;
+                return (unsigned)(b < 1 ? 1 : (b > 256 ? 256 : b));
+            };
+            hipLaunchKernelGGL((topk_to_f32_kernel<NV>), dim3(conv_blocks(n_sel)), dim3(256), 0, st,
+                               (int64_t)n_sel, sel, reinterpret_cast<const double *>(Ut), U32, unorm,
+                               (unsigned *)nullptr, max_bits);
+            hipLaunchKernelGGL((topk_to_f32_kernel<NV>), dim3(conv_blocks(n_items)), dim3(256), 0,
                                st, n_items, (const int32_t *)nullptr,
-                               reinterpret_cast<const double *>(Vt), kp, V32, (float *)nullptr,
+                               reinterpret_cast<const double *>(Vt), V32, (float *)nullptr,
                                vnorm_bits, max_bits + 1);
             hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, st,
                                n_sel, ident);
